@@ -1,0 +1,232 @@
+/*
+ * mrpdr.h -- C ABI of the MI355X wave-at-a-time PDR codec.
+ *
+ * This is the drop-in boundary for MRNet's packet marshalling path.  Where the
+ * reference packs one packet at a time through Packet::encode_pdr_data /
+ * decode_pdr_data and the pdr_* primitives, a caller hands this library a WAVE:
+ * n packets that share one format string, as device-resident buffers.
+ *
+ *   wire side     arena (bytes) + per-packet offsets/lengths; the bytes of every
+ *                 packet are exactly what src/pdr.c writes (no padding inside a
+ *                 packet; sender's native byte order; receiver makes right)
+ *   decoded side  one column per format token (struct mrpdr_column)
+ *
+ * Conventions
+ *   - every function returns bool_t-style int32_t: 1 = TRUE, 0 = FALSE
+ *     (src/pdr.h:40-58); on FALSE mrpdr_last_error() describes the reason
+ *   - all data pointers are DEVICE pointers unless the name ends in _host
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on
+ *     it unless a *_host output is requested (then the call synchronises it)
+ *   - nothing is thrown across this boundary; no torch/C++ types appear in it
+ *   - a mrpdr_ctx owns a small device workspace; calls using the same ctx must
+ *     not overlap in time (use one ctx per calling thread / stream)
+ *   - the device is little-endian: mrpdr_local_byteorder() == 0
+ */
+#ifndef MRPDR_H
+#define MRPDR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* DataType codes -- identical to include/mrnet/DataElement.h:27-45 */
+enum mrpdr_type {
+    MRPDR_UNKNOWN_T = 0, MRPDR_CHAR_T, MRPDR_UCHAR_T,
+    MRPDR_CHAR_ARRAY_T, MRPDR_UCHAR_ARRAY_T,
+    MRPDR_STRING_T, MRPDR_STRING_ARRAY_T,
+    MRPDR_INT16_T, MRPDR_UINT16_T,
+    MRPDR_INT16_ARRAY_T, MRPDR_UINT16_ARRAY_T,
+    MRPDR_INT32_T, MRPDR_UINT32_T,
+    MRPDR_INT32_ARRAY_T, MRPDR_UINT32_ARRAY_T,
+    MRPDR_INT64_T, MRPDR_UINT64_T,
+    MRPDR_INT64_ARRAY_T, MRPDR_UINT64_ARRAY_T,
+    MRPDR_FLOAT_T, MRPDR_DOUBLE_T,
+    MRPDR_FLOAT_ARRAY_T, MRPDR_DOUBLE_ARRAY_T,
+    MRPDR_CHAR_LRG_ARRAY_T, MRPDR_UCHAR_LRG_ARRAY_T,
+    MRPDR_STRING_LRG_ARRAY_T,
+    MRPDR_INT16_LRG_ARRAY_T, MRPDR_UINT16_LRG_ARRAY_T,
+    MRPDR_INT32_LRG_ARRAY_T, MRPDR_UINT32_LRG_ARRAY_T,
+    MRPDR_INT64_LRG_ARRAY_T, MRPDR_UINT64_LRG_ARRAY_T,
+    MRPDR_FLOAT_LRG_ARRAY_T, MRPDR_DOUBLE_LRG_ARRAY_T
+};
+
+/* pdr_byteorder, src/pdr.h:70-73 */
+enum mrpdr_byteorder { MRPDR_LITTLEENDIAN = 0, MRPDR_BIGENDIAN = 1 };
+
+/* field kinds */
+enum mrpdr_kind { MRPDR_SCALAR = 0, MRPDR_ARRAY = 1, MRPDR_STRING = 2, MRPDR_STRING_ARRAY = 3 };
+
+/* filter operators: TFILTER_SUM / MIN / MAX / AVG (src/FilterDefinitions.C:90-645) */
+enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 3 };
+
+/*
+ * Shape of the reduction a filter call applies to a wave.
+ *   MRPDR_SHAPE_FLAT  one left fold over all n packets, i.e. exactly one call of the
+ *                     reference's tfilter_* on the whole wave (serial; exact for every
+ *                     type and operator at any n)
+ *   MRPDR_SHAPE_TREE  the same fold applied level by level over a fixed tree, the way
+ *                     an MRNet tree applies it at every internal node:
+ *                     fan-in 4, then 2,2,2,2,2,2, then 4, then all remaining nodes
+ *                     (groups are consecutive packets; a group with no packet is
+ *                     skipped).  Integer SUM and NaN-free MIN/MAX give the same bits
+ *                     as FLAT; float SUM and every AVG depend on the shape.
+ */
+enum mrpdr_shape { MRPDR_SHAPE_FLAT = 0, MRPDR_SHAPE_TREE = 1 };
+
+/* fan-ins of MRPDR_SHAPE_TREE, 0 = all remaining nodes */
+#define MRPDR_TREE_LEVELS 9
+#define MRPDR_TREE_FANINS { 4, 2, 2, 2, 2, 2, 2, 4, 0 }
+
+typedef struct mrpdr_ctx mrpdr_ctx;
+typedef struct mrpdr_fmt mrpdr_fmt;
+
+/*
+ * One decoded field of a wave (device memory).
+ *   scalar        values = T[n]
+ *   array         counts[n] elements per packet, offs[n+1] = exclusive scan of counts,
+ *                 values = the packed elements (16-byte aligned base)
+ *   string        as an array of bytes; a string counts strlen+1 (the NUL travels)
+ * capacity = number of ELEMENTS values can hold (checked on decode).
+ * Replaces DataElement / DataValue (include/mrnet/DataElement.h:13-108).
+ */
+typedef struct mrpdr_column {
+    void     *values;
+    uint64_t *counts;
+    uint64_t *offs;
+    uint64_t  capacity;
+} mrpdr_column;
+
+/*
+ * Where the wire bytes of the wave live.  Packet i occupies
+ *   base + offsets[i] .. + lens[i]            when offsets != NULL
+ *   base + i*stride   .. + lens[i]            when offsets == NULL (packed layout)
+ * lens == NULL means "every packet has the format's fixed length" (scalar-only
+ * formats).  The reference keeps each packet's buffer in its own malloc block
+ * (src/Packet.C:69, src/Message.C:130-135); the arena replaces those blocks.
+ */
+typedef struct mrpdr_wire {
+    uint8_t        *base;
+    const uint64_t *offsets;
+    const uint64_t *lens;
+    uint64_t        stride;
+    uint64_t        bytes;     /* size of the arena in bytes (bounds) */
+} mrpdr_wire;
+
+/* ---- library ----------------------------------------------------------- */
+const char *mrpdr_version(void);
+/* Text of the last failure on the calling thread. */
+const char *mrpdr_last_error(void);
+/* pdrmem_getbo(), src/pdr_mem.c:421-428 */
+int32_t     mrpdr_local_byteorder(void);
+
+/* Workspace for scans and filter partials on `device`; max_packets bounds n of
+ * every later call with this ctx. */
+mrpdr_ctx  *mrpdr_ctx_create(int32_t device, uint64_t max_packets);
+void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
+/* Sticky device-side status: 0 = fine, bit 0 = a decode ran out of column capacity.
+ * Synchronises `stream`. */
+int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
+
+/* ---- format strings ------------------------------------------------------
+ * Fmt2Type (src/DataElement.C:205-297) + the " \t\n%" tokenising of
+ * Packet::pdr_packet_data (src/Packet.C:608-619), done once per format instead of
+ * once per packet.  NULL on an unknown token or more than 32 tokens. */
+mrpdr_fmt  *mrpdr_fmt_compile(const char *fmt);
+void        mrpdr_fmt_free(mrpdr_fmt *f);
+int32_t     mrpdr_fmt_nfields(const mrpdr_fmt *f);
+int32_t     mrpdr_fmt_field_type(const mrpdr_fmt *f, int32_t field);
+int32_t     mrpdr_fmt_field_kind(const mrpdr_fmt *f, int32_t field);
+int32_t     mrpdr_fmt_field_width(const mrpdr_fmt *f, int32_t field);
+/* 1 when every token is a scalar: all packets then have the same length */
+int32_t     mrpdr_fmt_is_fixed(const mrpdr_fmt *f);
+/* bytes of scalars and length prefixes per packet (= data length for fixed formats) */
+uint64_t    mrpdr_fmt_fixed_bytes(const mrpdr_fmt *f);
+const char *mrpdr_fmt_string(const mrpdr_fmt *f);
+
+/* ---- sizing: pdr_sizeof for a whole wave -----------------------------------
+ * Replaces the dry-run encode pdr_sizeof(Packet::pdr_packet_data) that
+ * Packet::encode_pdr_data runs per packet (src/Packet.C:61, src/pdr_sizeof.c:120-140).
+ * lens[i] = encoded data length of packet i; offsets[0..n] = exclusive prefix scan of
+ * lens rounded up to `align` (1, or a power of two up to 256) -- the arena layout.
+ * total_host (optional) receives offsets[n] and synchronises the stream. */
+int32_t mrpdr_wave_sizeof(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
+                          uint64_t n, uint32_t align, uint64_t *lens, uint64_t *offsets,
+                          uint64_t *total_host, void *stream);
+
+/* ---- encode: Packet::encode_pdr_data for a whole wave -------------------------
+ * (src/Packet.C:54-85 -> pdr_packet_data ENCODE, src/Packet.C:594-845 -> pdrmem_put*,
+ * src/pdr_mem.c:22-343, pdr_array/pdr_bytes/pdr_string, src/pdr.c:212-472).
+ * Always writes native (little-endian) order, like the reference encoder.
+ * Padding bytes of a packed fixed layout (stride > length) are written as zero. */
+int32_t mrpdr_wave_encode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
+                          uint64_t n, const mrpdr_wire *wire, void *stream);
+
+/* ---- decode: Packet::decode_pdr_data for a whole wave -------------------------
+ * (src/Packet.C:106-133 -> pdr_packet_data DECODE -> pdrmem_get* / pdrmem_get*_swap,
+ * src/pdr_mem.c:40-315; byte reversal of src/byte_order.c:8-17 when
+ * sender_byteorder != local).
+ *
+ * begin : walks every packet: scalar columns, counts[] of array/string fields and
+ *         ok[i] (1 = packet decoded, 0 = truncated / oversize count; a failed packet
+ *         yields zero for the failed field and all later ones), then scans counts
+ *         into offs[].  totals_host (optional, one entry per field) receives the element
+ *         total of every array/string field and synchronises the stream.
+ * finish: moves (and byte-reverses) the array/string payloads into values[].
+ * mrpdr_wave_decode = begin + finish. */
+int32_t mrpdr_wave_decode_begin(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                uint64_t n, int32_t sender_byteorder, mrpdr_column *cols,
+                                int32_t *ok, uint64_t *totals_host, void *stream);
+int32_t mrpdr_wave_decode_finish(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                 uint64_t n, int32_t sender_byteorder, mrpdr_column *cols,
+                                 void *stream);
+int32_t mrpdr_wave_decode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                          uint64_t n, int32_t sender_byteorder, mrpdr_column *cols,
+                          int32_t *ok, void *stream);
+
+/* ---- packet headers --------------------------------------------------------
+ * Packet::pdr_packet_header (src/Packet.C:557-593) for n packets of one format:
+ *   u32 stream_id | i32 tag | u32 src_rank | u32 strlen(fmt)+1 | fmt,NUL |
+ *   u64 ndest (= 0) | u8 byteorder
+ * stream_ids / tags / src_ranks are device columns; a NULL column means the scalar
+ * argument applies to every packet.  Header i is written at hdrs + i*hdr_stride.
+ * mrpdr_header_bytes gives the header length for a format (no destination list). */
+uint64_t mrpdr_header_bytes(const mrpdr_fmt *f);
+int32_t  mrpdr_wave_encode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
+                                   uint32_t stream_id, const uint32_t *stream_ids,
+                                   int32_t tag, const int32_t *tags,
+                                   uint32_t src_rank, const uint32_t *src_ranks,
+                                   uint8_t *hdrs, uint64_t hdr_stride, void *stream);
+/* Packet::decode_pdr_header (src/Packet.C:87-104): byte order of a header is its own
+ * last byte.  Header i is hdrs + hdr_offsets[i] (or i*hdr_stride when hdr_offsets is
+ * NULL), hdr_lens[i] long (or hdr_stride when NULL).  Outputs (any may be NULL):
+ * stream_ids, tags, src_ranks, byteorders (u8), ndests (u64), and ok[i] = 1 when the
+ * header parsed AND its format string equals f's. */
+int32_t  mrpdr_wave_decode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
+                                   const uint8_t *hdrs, const uint64_t *hdr_offsets,
+                                   const uint64_t *hdr_lens, uint64_t hdr_stride,
+                                   uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
+                                   uint8_t *byteorders, uint64_t *ndests, int32_t *ok,
+                                   void *stream);
+
+/* ---- filters: tfilter_Sum / Min / Max / Avg over a wave ---------------------------
+ * (src/FilterDefinitions.C:90-645; arithmetic helpers :1925-2136.)
+ * `type` is a scalar DataType.  values = T[n] with a byte stride of value_stride
+ * (sizeof(T) for a decoded column); counts (AVG only) = int32[n] with count_stride.
+ * swap != 0 byte-reverses every value and count while loading, so the call can run
+ * straight on the wire bytes of a fixed-format wave (fused decode + reduce):
+ *   values = wire.base, value_stride = packet stride, counts = wire.base + sizeof(T).
+ * result (device, 16 bytes): the data bytes of the output packet the reference filter
+ * would build -- T value, then for AVG the int32 count -- in native order, zero padded.
+ * result_ok (device int32, optional): 0 when n == 0 or an AVG count sum was zero. */
+int32_t mrpdr_wave_filter(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shape,
+                          const void *values, uint64_t value_stride,
+                          const void *counts, uint64_t count_stride,
+                          uint64_t n, int32_t swap,
+                          void *result, int32_t *result_ok, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRPDR_H */

@@ -1,0 +1,86 @@
+"""ctypes declarations of the C ABI in include/mrpdr.h (mrnet_amd/lib/libmrpdr.so).
+
+There is no CPU fallback: if the HIP library is missing, importing this module
+raises, and every compute entry point fails without a GPU.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmrpdr.so")
+
+# every symbol include/mrpdr.h declares
+SYMBOLS = (
+    "mrpdr_version", "mrpdr_last_error", "mrpdr_local_byteorder",
+    "mrpdr_ctx_create", "mrpdr_ctx_destroy", "mrpdr_ctx_status",
+    "mrpdr_fmt_compile", "mrpdr_fmt_free", "mrpdr_fmt_nfields", "mrpdr_fmt_field_type",
+    "mrpdr_fmt_field_kind", "mrpdr_fmt_field_width", "mrpdr_fmt_is_fixed",
+    "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_string",
+    "mrpdr_wave_sizeof", "mrpdr_wave_encode",
+    "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
+    "mrpdr_header_bytes", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
+    "mrpdr_wave_filter",
+)
+
+
+class Column(C.Structure):
+    """struct mrpdr_column"""
+    _fields_ = [("values", C.c_void_p), ("counts", C.c_void_p), ("offs", C.c_void_p),
+                ("capacity", C.c_uint64)]
+
+
+class Wire(C.Structure):
+    """struct mrpdr_wire"""
+    _fields_ = [("base", C.c_void_p), ("offsets", C.c_void_p), ("lens", C.c_void_p),
+                ("stride", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mrnet_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, u32 = C.c_void_p, C.c_uint64, C.c_int32, C.c_uint32
+    sig = {
+        "mrpdr_version": (C.c_char_p, []),
+        "mrpdr_last_error": (C.c_char_p, []),
+        "mrpdr_local_byteorder": (i32, []),
+        "mrpdr_ctx_create": (vp, [i32, u64]),
+        "mrpdr_ctx_destroy": (None, [vp]),
+        "mrpdr_ctx_status": (i32, [vp, vp, C.POINTER(u32)]),
+        "mrpdr_fmt_compile": (vp, [C.c_char_p]),
+        "mrpdr_fmt_free": (None, [vp]),
+        "mrpdr_fmt_nfields": (i32, [vp]),
+        "mrpdr_fmt_field_type": (i32, [vp, i32]),
+        "mrpdr_fmt_field_kind": (i32, [vp, i32]),
+        "mrpdr_fmt_field_width": (i32, [vp, i32]),
+        "mrpdr_fmt_is_fixed": (i32, [vp]),
+        "mrpdr_fmt_fixed_bytes": (u64, [vp]),
+        "mrpdr_fmt_string": (C.c_char_p, [vp]),
+        "mrpdr_wave_sizeof": (i32, [vp, vp, C.POINTER(Column), u64, u32, vp, vp, C.POINTER(u64), vp]),
+        "mrpdr_wave_encode": (i32, [vp, vp, C.POINTER(Column), u64, C.POINTER(Wire), vp]),
+        "mrpdr_wave_decode_begin": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp,
+                                          C.POINTER(u64), vp]),
+        "mrpdr_wave_decode_finish": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp]),
+        "mrpdr_wave_decode": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp, vp]),
+        "mrpdr_header_bytes": (u64, [vp]),
+        "mrpdr_wave_encode_headers": (i32, [vp, vp, u64, u32, vp, i32, vp, u32, vp, vp, u64, vp]),
+        "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
+        "mrpdr_wave_filter": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(L, name)           # AttributeError if the library lacks a declared symbol
+        fn.restype, fn.argtypes = sig[name]
+    _lib = L
+    return L
+
+
+def last_error():
+    return load().mrpdr_last_error().decode()

@@ -1,0 +1,112 @@
+// Shared host/device definitions of the wave codec.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mrpdr.h"
+
+#define MRPDR_MAXF 32          // tokens per format string
+#define MRPDR_TPB 256          // threads per workgroup: 4 wavefronts of 64
+
+// One format token as the kernels see it.
+struct FieldDev {
+    uint8_t  kind;          // mrpdr_kind
+    uint8_t  width;         // element width in bytes (strings: 1)
+    uint8_t  large;         // %A* token: count bound UINT64_MAX instead of INT32_MAX
+    uint8_t  type;          // DataType code
+    uint32_t fixed_before;  // bytes of scalars and length prefixes that precede this field
+};
+
+struct FmtDev {
+    int32_t  nf;
+    uint32_t fixed_bytes;   // all scalars + all length prefixes
+    FieldDev f[MRPDR_MAXF];
+};
+
+struct ColsDev {
+    void     *values[MRPDR_MAXF];
+    uint64_t *counts[MRPDR_MAXF];
+    uint64_t *offs[MRPDR_MAXF];
+    uint64_t  cap[MRPDR_MAXF];
+};
+
+struct WireDev {
+    uint8_t        *base;
+    const uint64_t *offsets;
+    const uint64_t *lens;
+    uint64_t        stride;
+    uint64_t        bytes;
+};
+
+// Length prefix of a variable field: u64 element count for arrays (src/pdr.c:425),
+// u32 strlen+1 for strings (src/pdr.c:295-297).
+__host__ __device__ inline uint32_t prefix_bytes(uint8_t kind)
+{
+    return kind == MRPDR_ARRAY ? 8u : (kind == MRPDR_STRING ? 4u : 0u);
+}
+
+__device__ inline uint64_t pkt_off(const WireDev &w, uint64_t i)
+{
+    return w.offsets ? w.offsets[i] : i * w.stride;
+}
+
+__device__ inline uint64_t pkt_len(const WireDev &w, const FmtDev &fmt, uint64_t i)
+{
+    return w.lens ? w.lens[i] : (uint64_t)fmt.fixed_bytes;
+}
+
+// ---- byte-granular loads/stores at any alignment --------------------------------
+// gfx950 under the HSA ABI runs with unaligned global access enabled, so these
+// compile to single global_load/store instructions.
+template <typename U> __device__ inline U ld_u(const uint8_t *p)
+{
+    U v;
+    __builtin_memcpy(&v, p, sizeof(U));
+    return v;
+}
+template <typename U> __device__ inline void st_u(uint8_t *p, U v)
+{
+    __builtin_memcpy(p, &v, sizeof(U));
+}
+
+__device__ inline uint16_t bswap_u(uint16_t v) { return __builtin_bswap16(v); }
+__device__ inline uint32_t bswap_u(uint32_t v) { return __builtin_bswap32(v); }
+__device__ inline uint64_t bswap_u(uint64_t v) { return __builtin_bswap64(v); }
+__device__ inline uint8_t  bswap_u(uint8_t v)  { return v; }
+
+// Load a W-byte scalar from the wire as an unsigned integer, reversing its bytes
+// when the sender's order differs (pdrmem_get*_swap, src/pdr_mem.c:96-315).
+template <int W> struct UIntOf;
+template <> struct UIntOf<1> { typedef uint8_t  type; };
+template <> struct UIntOf<2> { typedef uint16_t type; };
+template <> struct UIntOf<4> { typedef uint32_t type; };
+template <> struct UIntOf<8> { typedef uint64_t type; };
+
+template <int W> __device__ inline uint64_t ld_wire(const uint8_t *p, bool swap)
+{
+    typedef typename UIntOf<W>::type U;
+    U v = ld_u<U>(p);
+    if (swap) v = bswap_u(v);
+    return (uint64_t)v;
+}
+
+__device__ inline uint64_t ld_wire_w(const uint8_t *p, int w, bool swap)
+{
+    switch (w) {
+    case 1: return ld_wire<1>(p, swap);
+    case 2: return ld_wire<2>(p, swap);
+    case 4: return ld_wire<4>(p, swap);
+    default: return ld_wire<8>(p, swap);
+    }
+}
+
+__device__ inline void st_w(uint8_t *p, int w, uint64_t v)
+{
+    switch (w) {
+    case 1: st_u<uint8_t>(p, (uint8_t)v); break;
+    case 2: st_u<uint16_t>(p, (uint16_t)v); break;
+    case 4: st_u<uint32_t>(p, (uint32_t)v); break;
+    default: st_u<uint64_t>(p, v); break;
+    }
+}

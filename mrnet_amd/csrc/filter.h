@@ -1,0 +1,229 @@
+// tfilter_Sum / tfilter_Min / tfilter_Max / tfilter_Avg over a wave.
+//
+// Reference (src/FilterDefinitions.C): each filter is a left fold over the packets
+// of a wave in the element's own C type --
+//   Sum  result = 0; result = result + x_i                          (:100-149, :1925-1964)
+//   Max  result = x_0; result = (result > x_i) ? result : x_i       (:237-286, :2090-2136)
+//   Min  result = x_0; result = (result < x_i) ? result : x_i       (:374-424, :2042-2088)
+//   Avg  packets are (value, count): result = sum of value*count computed in T,
+//        n = sum of counts (int); output (result / n, n)            (:514-561, :1966-2040)
+// 8- and 16-bit integers are promoted to int and truncated back; integer division
+// truncates toward zero; float stays float.
+//
+// Folder applies exactly that fold to a short list of children.  The tree shape
+// applies it level by level (lane: 4 packets; six pairings across the 64 lanes of a
+// wavefront; the 4 wavefronts of a workgroup; all workgroups), the flat shape applies
+// it once to the whole wave from one lane.
+#pragma once
+
+#include "common.h"
+
+#define FILTER_LEAF 4                                   // packets per lane
+#define FILTER_TILE (MRPDR_TPB * FILTER_LEAF)           // packets per workgroup
+#define FLAT_TILE 2048                                  // packets staged in LDS per step
+
+struct Partial {            // one node of the tree, as stored between launches
+    uint64_t bits;          // value, low bytes
+    int32_t  cnt;           // AVG: summed count
+    int32_t  present;       // 0 = no packet below this node
+};
+
+template <typename T> __device__ inline T mul_cnt(T v, int32_t n);     // value * count, reference casts
+template <typename T> __device__ inline T div_cnt(T v, int32_t n);     // value / count, reference casts
+
+#define SMALL_INT_OPS(T)                                                              \
+    template <> __device__ inline T mul_cnt<T>(T v, int32_t n) { return (T)((int32_t)v * n); } \
+    template <> __device__ inline T div_cnt<T>(T v, int32_t n) { return (T)((int32_t)v / n); }
+SMALL_INT_OPS(int8_t) SMALL_INT_OPS(uint8_t) SMALL_INT_OPS(int16_t) SMALL_INT_OPS(uint16_t)
+#undef SMALL_INT_OPS
+template <> __device__ inline int32_t  mul_cnt<int32_t>(int32_t v, int32_t n)   { return v * n; }
+template <> __device__ inline int32_t  div_cnt<int32_t>(int32_t v, int32_t n)   { return v / n; }
+template <> __device__ inline uint32_t mul_cnt<uint32_t>(uint32_t v, int32_t n) { return v * (uint32_t)n; }
+template <> __device__ inline uint32_t div_cnt<uint32_t>(uint32_t v, int32_t n) { return v / (uint32_t)n; }
+template <> __device__ inline int64_t  mul_cnt<int64_t>(int64_t v, int32_t n)   { return v * (int64_t)n; }
+template <> __device__ inline int64_t  div_cnt<int64_t>(int64_t v, int32_t n)   { return v / (int64_t)n; }
+template <> __device__ inline uint64_t mul_cnt<uint64_t>(uint64_t v, int32_t n) { return v * (uint64_t)(int64_t)n; }
+template <> __device__ inline uint64_t div_cnt<uint64_t>(uint64_t v, int32_t n) { return v / (uint64_t)(int64_t)n; }
+template <> __device__ inline float    mul_cnt<float>(float v, int32_t n)       { return v * (float)n; }
+template <> __device__ inline float    div_cnt<float>(float v, int32_t n)       { return v / (float)n; }
+template <> __device__ inline double   mul_cnt<double>(double v, int32_t n)     { return v * (double)n; }
+template <> __device__ inline double   div_cnt<double>(double v, int32_t n)     { return v / (double)n; }
+
+template <int OP, typename T> struct Folder {
+    T res;
+    int32_t cnt;
+    bool any;
+    __device__ inline void init() { res = (T)0; cnt = 0; any = false; }
+    __device__ inline void add(T x, int32_t c)
+    {
+        if (OP == MRPDR_SUM) {
+            res = (T)(res + x);
+        } else if (OP == MRPDR_MAX) {
+            res = any ? ((res > x) ? res : x) : x;
+        } else if (OP == MRPDR_MIN) {
+            res = any ? ((res < x) ? res : x) : x;
+        } else {
+            res = (T)(res + mul_cnt<T>(x, c));
+            cnt += c;
+        }
+        any = true;
+    }
+    // false: the node is absent (no child, or an AVG whose counts sum to zero)
+    __device__ inline bool finish()
+    {
+        if (!any) return false;
+        if (OP == MRPDR_AVG) {
+            if (cnt == 0) return false;
+            res = div_cnt<T>(res, cnt);
+        }
+        return true;
+    }
+};
+
+template <typename T> __device__ inline uint64_t to_bits(T v)
+{
+    uint64_t b = 0;
+    __builtin_memcpy(&b, &v, sizeof(T));
+    return b;
+}
+template <typename T> __device__ inline T from_bits(uint64_t b)
+{
+    T v;
+    __builtin_memcpy(&v, &b, sizeof(T));
+    return v;
+}
+
+struct FilterIn {
+    const uint8_t *values;  uint64_t value_stride;
+    const uint8_t *counts;  uint64_t count_stride;
+    uint64_t n;
+    int32_t  swap;
+};
+
+template <typename T> __device__ inline T load_value(const FilterIn &in, uint64_t i)
+{
+    return from_bits<T>(ld_wire<sizeof(T)>(in.values + i * in.value_stride, in.swap != 0));
+}
+__device__ inline int32_t load_count(const FilterIn &in, uint64_t i)
+{
+    return (int32_t)(uint32_t)ld_wire<4>(in.counts + i * in.count_stride, in.swap != 0);
+}
+
+// The data bytes of the filter's output packet: T value [, int32 count], no padding
+// between them (Packet::pdr_packet_data ENCODE of "%T" or "%T %d").
+template <int OP, typename T>
+__device__ inline void write_result(uint8_t *result, int32_t *result_ok, bool present, T v, int32_t cnt)
+{
+    for (int b = 0; b < 16; b++) result[b] = 0;
+    if (present) {
+        st_u<T>(result, v);
+        if (OP == MRPDR_AVG) st_u<int32_t>(result + sizeof(T), cnt);
+    }
+    if (result_ok) *result_ok = present ? 1 : 0;
+}
+
+// ---- tree shape, levels 0..7: one partial per workgroup -------------------------
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Partial *partials)
+{
+    __shared__ Partial wave_part[MRPDR_TPB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t first = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)threadIdx.x * FILTER_LEAF;
+
+    // level 0: this lane's packets, in order
+    Folder<OP, T> fo;
+    fo.init();
+#pragma unroll
+    for (int k = 0; k < FILTER_LEAF; k++) {
+        const uint64_t i = first + k;
+        if (i < in.n) fo.add(load_value<T>(in, i), OP == MRPDR_AVG ? load_count(in, i) : 1);
+    }
+    bool present = fo.finish();
+    T v = fo.res;
+    int32_t cnt = fo.cnt;
+
+    // levels 1..6: pair neighbours across the wavefront; the lower lane is the left child
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const uint64_t ob = __shfl_xor((unsigned long long)to_bits<T>(v), m, 64);
+        const int32_t  oc = __shfl_xor(cnt, m, 64);
+        const int      op = __shfl_xor((int)present, m, 64);
+        const bool right = (lane & m) != 0;
+        const T lv = right ? from_bits<T>(ob) : v;   const T rv = right ? v : from_bits<T>(ob);
+        const int32_t lc = right ? oc : cnt;         const int32_t rc = right ? cnt : oc;
+        const bool lp = right ? (op != 0) : present; const bool rp = right ? present : (op != 0);
+        Folder<OP, T> g;
+        g.init();
+        if (lp) g.add(lv, lc);
+        if (rp) g.add(rv, rc);
+        present = g.finish();
+        v = g.res; cnt = g.cnt;
+    }
+
+    // level 7: the wavefronts of this workgroup
+    if (lane == 0) {
+        wave_part[wave].bits = to_bits<T>(v);
+        wave_part[wave].cnt = cnt;
+        wave_part[wave].present = present ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Folder<OP, T> g;
+        g.init();
+        for (int w = 0; w < MRPDR_TPB / 64; w++)
+            if (wave_part[w].present) g.add(from_bits<T>(wave_part[w].bits), wave_part[w].cnt);
+        Partial out;
+        out.present = g.finish() ? 1 : 0;
+        out.bits = to_bits<T>(g.res);
+        out.cnt = g.cnt;
+        partials[blockIdx.x] = out;
+    }
+}
+
+// ---- tree shape, last level: all workgroup partials, in order ---------------------
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_top(const Partial *partials, uint64_t np,
+                                                               uint8_t *result, int32_t *result_ok)
+{
+    __shared__ Partial stage[FLAT_TILE];
+    Folder<OP, T> g;
+    g.init();
+    for (uint64_t base = 0; base < np; base += FLAT_TILE) {
+        const uint32_t m = (uint32_t)((np - base) < FLAT_TILE ? (np - base) : FLAT_TILE);
+        for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) stage[k] = partials[base + k];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t k = 0; k < m; k++)
+                if (stage[k].present) g.add(from_bits<T>(stage[k].bits), stage[k].cnt);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool present = g.finish();
+        write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
+    }
+}
+
+// ---- flat shape: one left fold over the whole wave ------------------------------
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t *result, int32_t *result_ok)
+{
+    __shared__ T       sv[FLAT_TILE];
+    __shared__ int32_t sc[FLAT_TILE];
+    Folder<OP, T> g;
+    g.init();
+    for (uint64_t base = 0; base < in.n; base += FLAT_TILE) {
+        const uint32_t m = (uint32_t)((in.n - base) < FLAT_TILE ? (in.n - base) : FLAT_TILE);
+        for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) {
+            sv[k] = load_value<T>(in, base + k);
+            sc[k] = OP == MRPDR_AVG ? load_count(in, base + k) : 1;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t k = 0; k < m; k++) g.add(sv[k], sc[k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const bool present = g.finish();
+        write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
+    }
+}

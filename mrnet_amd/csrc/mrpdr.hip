@@ -1,0 +1,594 @@
+// C ABI of the wave codec (include/mrpdr.h): argument checks, format compiler,
+// kernel launches.  gfx950 only.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+
+#include "common.h"
+#include "scan.h"
+#include "rows.h"
+#include "copy.h"
+#include "filter.h"
+#include "header.h"
+
+// ---------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int32_t fail(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return 0;
+}
+
+#define HIP_OK(call)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (call);                                                       \
+        if (e_ != hipSuccess) return fail("%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+#define LAUNCHED(name)                                                                \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) return fail("launch %s: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char *mrpdr_version(void) { return "mrpdr 0.1 (gfx950)"; }
+extern "C" const char *mrpdr_last_error(void) { return g_err; }
+extern "C" int32_t mrpdr_local_byteorder(void) { return MRPDR_LITTLEENDIAN; }
+
+// ---------------------------------------------------------------------------
+// format strings
+// ---------------------------------------------------------------------------
+struct mrpdr_fmt {
+    FmtDev dev;
+    char  *text;
+    int    fixed;        // all scalar
+    int    nvar;
+};
+
+// Fmt2Type, src/DataElement.C:205-297
+static int token_type(const char *tok)
+{
+    static const struct { const char *tok; int type; } table[] = {
+        {"c", MRPDR_CHAR_T}, {"uc", MRPDR_UCHAR_T}, {"hd", MRPDR_INT16_T}, {"uhd", MRPDR_UINT16_T},
+        {"d", MRPDR_INT32_T}, {"ud", MRPDR_UINT32_T}, {"ld", MRPDR_INT64_T}, {"uld", MRPDR_UINT64_T},
+        {"f", MRPDR_FLOAT_T}, {"lf", MRPDR_DOUBLE_T}, {"s", MRPDR_STRING_T},
+        {"ac", MRPDR_CHAR_ARRAY_T}, {"auc", MRPDR_UCHAR_ARRAY_T}, {"ahd", MRPDR_INT16_ARRAY_T},
+        {"auhd", MRPDR_UINT16_ARRAY_T}, {"ad", MRPDR_INT32_ARRAY_T}, {"aud", MRPDR_UINT32_ARRAY_T},
+        {"ald", MRPDR_INT64_ARRAY_T}, {"auld", MRPDR_UINT64_ARRAY_T}, {"af", MRPDR_FLOAT_ARRAY_T},
+        {"alf", MRPDR_DOUBLE_ARRAY_T}, {"as", MRPDR_STRING_ARRAY_T},
+        {"Ac", MRPDR_CHAR_LRG_ARRAY_T}, {"Auc", MRPDR_UCHAR_LRG_ARRAY_T},
+        {"Ahd", MRPDR_INT16_LRG_ARRAY_T}, {"Auhd", MRPDR_UINT16_LRG_ARRAY_T},
+        {"Ad", MRPDR_INT32_LRG_ARRAY_T}, {"Aud", MRPDR_UINT32_LRG_ARRAY_T},
+        {"Ald", MRPDR_INT64_LRG_ARRAY_T}, {"Auld", MRPDR_UINT64_LRG_ARRAY_T},
+        {"Af", MRPDR_FLOAT_LRG_ARRAY_T}, {"Alf", MRPDR_DOUBLE_LRG_ARRAY_T},
+        {"As", MRPDR_STRING_LRG_ARRAY_T},
+    };
+    for (size_t i = 0; i < sizeof table / sizeof table[0]; i++)
+        if (strcmp(tok, table[i].tok) == 0) return table[i].type;
+    return MRPDR_UNKNOWN_T;
+}
+
+static int type_kind(int t)
+{
+    switch (t) {
+    case MRPDR_CHAR_T: case MRPDR_UCHAR_T: case MRPDR_INT16_T: case MRPDR_UINT16_T:
+    case MRPDR_INT32_T: case MRPDR_UINT32_T: case MRPDR_INT64_T: case MRPDR_UINT64_T:
+    case MRPDR_FLOAT_T: case MRPDR_DOUBLE_T: return MRPDR_SCALAR;
+    case MRPDR_STRING_T: return MRPDR_STRING;
+    case MRPDR_STRING_ARRAY_T: case MRPDR_STRING_LRG_ARRAY_T: return MRPDR_STRING_ARRAY;
+    case MRPDR_UNKNOWN_T: return -1;
+    default: return MRPDR_ARRAY;
+    }
+}
+
+static int type_width(int t)
+{
+    switch (t) {
+    case MRPDR_INT16_T: case MRPDR_UINT16_T: case MRPDR_INT16_ARRAY_T: case MRPDR_UINT16_ARRAY_T:
+    case MRPDR_INT16_LRG_ARRAY_T: case MRPDR_UINT16_LRG_ARRAY_T: return 2;
+    case MRPDR_INT32_T: case MRPDR_UINT32_T: case MRPDR_FLOAT_T: case MRPDR_INT32_ARRAY_T:
+    case MRPDR_UINT32_ARRAY_T: case MRPDR_FLOAT_ARRAY_T: case MRPDR_INT32_LRG_ARRAY_T:
+    case MRPDR_UINT32_LRG_ARRAY_T: case MRPDR_FLOAT_LRG_ARRAY_T: return 4;
+    case MRPDR_INT64_T: case MRPDR_UINT64_T: case MRPDR_DOUBLE_T: case MRPDR_INT64_ARRAY_T:
+    case MRPDR_UINT64_ARRAY_T: case MRPDR_DOUBLE_ARRAY_T: case MRPDR_INT64_LRG_ARRAY_T:
+    case MRPDR_UINT64_LRG_ARRAY_T: case MRPDR_DOUBLE_LRG_ARRAY_T: return 8;
+    case MRPDR_UNKNOWN_T: return 0;
+    default: return 1;
+    }
+}
+
+extern "C" mrpdr_fmt *mrpdr_fmt_compile(const char *fmt)
+{
+    if (!fmt) { fail("mrpdr_fmt_compile: NULL format"); return nullptr; }
+    static const char delim[] = " \t\n%";          // src/Packet.C:611
+    mrpdr_fmt *f = (mrpdr_fmt *)calloc(1, sizeof *f);
+    if (!f) { fail("mrpdr_fmt_compile: out of memory"); return nullptr; }
+    const char *p = fmt;
+    uint32_t fixed = 0;
+    for (;;) {
+        p += strspn(p, delim);
+        if (!*p) break;
+        size_t len = strcspn(p, delim);
+        char tok[16];
+        if (len >= sizeof tok) { fail("mrpdr_fmt_compile: unknown token in '%s'", fmt); free(f); return nullptr; }
+        memcpy(tok, p, len); tok[len] = 0;
+        p += len;
+        int t = token_type(tok);
+        if (t == MRPDR_UNKNOWN_T) { fail("mrpdr_fmt_compile: unknown token '%s' in '%s'", tok, fmt); free(f); return nullptr; }
+        if (f->dev.nf == MRPDR_MAXF) { fail("mrpdr_fmt_compile: more than %d tokens in '%s'", MRPDR_MAXF, fmt); free(f); return nullptr; }
+        FieldDev &fd = f->dev.f[f->dev.nf++];
+        fd.type = (uint8_t)t;
+        fd.kind = (uint8_t)type_kind(t);
+        fd.width = (uint8_t)type_width(t);
+        fd.large = (uint8_t)(t >= MRPDR_CHAR_LRG_ARRAY_T);
+        fd.fixed_before = fixed;
+        if (fd.kind == MRPDR_SCALAR) fixed += fd.width;
+        else { fixed += fd.kind == MRPDR_STRING ? 4 : 8; f->nvar++; }
+    }
+    f->dev.fixed_bytes = fixed;
+    f->fixed = f->nvar == 0;
+    f->text = strdup(fmt);
+    return f;
+}
+
+extern "C" void mrpdr_fmt_free(mrpdr_fmt *f)
+{
+    if (f) { free(f->text); free(f); }
+}
+extern "C" int32_t mrpdr_fmt_nfields(const mrpdr_fmt *f) { return f ? f->dev.nf : 0; }
+extern "C" int32_t mrpdr_fmt_field_type(const mrpdr_fmt *f, int32_t i)
+{
+    return (f && i >= 0 && i < f->dev.nf) ? f->dev.f[i].type : MRPDR_UNKNOWN_T;
+}
+extern "C" int32_t mrpdr_fmt_field_kind(const mrpdr_fmt *f, int32_t i)
+{
+    return (f && i >= 0 && i < f->dev.nf) ? f->dev.f[i].kind : -1;
+}
+extern "C" int32_t mrpdr_fmt_field_width(const mrpdr_fmt *f, int32_t i)
+{
+    return (f && i >= 0 && i < f->dev.nf) ? f->dev.f[i].width : 0;
+}
+extern "C" int32_t mrpdr_fmt_is_fixed(const mrpdr_fmt *f) { return f ? f->fixed : 0; }
+extern "C" uint64_t mrpdr_fmt_fixed_bytes(const mrpdr_fmt *f) { return f ? f->dev.fixed_bytes : 0; }
+extern "C" const char *mrpdr_fmt_string(const mrpdr_fmt *f) { return f ? f->text : ""; }
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+struct mrpdr_ctx {
+    int32_t   device;
+    uint64_t  max_packets;
+    uint8_t  *ws;             // device workspace
+    uint32_t *status;         // ws + 0
+    uint64_t *tile_sums;      // scan partials
+    uint64_t  ntile_sums;
+    Partial  *partials;       // filter partials
+    uint64_t  npartials;
+    uint64_t *totals;         // per-field totals gathered for the host
+    int32_t   num_cu;
+};
+
+extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
+{
+    int prev = 0;
+    if (hipGetDevice(&prev) != hipSuccess) { fail("mrpdr_ctx_create: no HIP device available"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fail("mrpdr_ctx_create: hipSetDevice(%d) failed", device); return nullptr; }
+    mrpdr_ctx *c = (mrpdr_ctx *)calloc(1, sizeof *c);
+    c->device = device;
+    c->max_packets = max_packets ? max_packets : 1;
+    c->ntile_sums = (c->max_packets + SCAN_TILE - 1) / SCAN_TILE + 1;
+    c->npartials = (c->max_packets + FILTER_TILE - 1) / FILTER_TILE + 1;
+    const size_t o_status = 0, o_totals = 256;
+    const size_t o_sums = o_totals + 256 * sizeof(uint64_t);
+    const size_t o_part = o_sums + ((c->ntile_sums * sizeof(uint64_t) + 255) & ~(size_t)255);
+    const size_t bytes = o_part + c->npartials * sizeof(Partial);
+    hipError_t e = hipMalloc((void **)&c->ws, bytes);
+    if (e == hipSuccess) e = hipMemset(c->ws, 0, bytes);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    (void)hipSetDevice(prev);
+    if (e != hipSuccess) {
+        fail("mrpdr_ctx_create: %s", hipGetErrorString(e));
+        free(c);
+        return nullptr;
+    }
+    c->status = (uint32_t *)(c->ws + o_status);
+    c->totals = (uint64_t *)(c->ws + o_totals);
+    c->tile_sums = (uint64_t *)(c->ws + o_sums);
+    c->partials = (Partial *)(c->ws + o_part);
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    return c;
+}
+
+extern "C" void mrpdr_ctx_destroy(mrpdr_ctx *c)
+{
+    if (!c) return;
+    (void)hipFree(c->ws);
+    free(c);
+}
+
+extern "C" int32_t mrpdr_ctx_status(mrpdr_ctx *c, void *stream, uint32_t *status_host)
+{
+    if (!c || !status_host) return fail("mrpdr_ctx_status: NULL argument");
+    HIP_OK(hipMemcpyAsync(status_host, c->status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// helpers
+// ---------------------------------------------------------------------------
+static inline uint32_t blocks_for(uint64_t n, uint32_t per_block)
+{
+    return (uint32_t)((n + per_block - 1) / per_block);
+}
+
+static int32_t check_common(const char *who, const mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n)
+{
+    if (!c) return fail("%s: NULL ctx", who);
+    if (!f) return fail("%s: NULL format", who);
+    if (n > c->max_packets) return fail("%s: n=%llu exceeds the ctx limit %llu", who,
+                                        (unsigned long long)n, (unsigned long long)c->max_packets);
+    for (int i = 0; i < f->dev.nf; i++)
+        if (f->dev.f[i].kind == MRPDR_STRING_ARRAY)
+            return fail("%s: string-array tokens (%%as / %%As) are not supported on the device", who);
+    return 1;
+}
+
+static int32_t fill_cols(const char *who, const mrpdr_fmt *f, const mrpdr_column *cols, uint64_t n,
+                         bool need_values, ColsDev *out)
+{
+    memset(out, 0, sizeof *out);
+    if (f->dev.nf && !cols) return fail("%s: NULL columns", who);
+    for (int i = 0; i < f->dev.nf; i++) {
+        const FieldDev &fd = f->dev.f[i];
+        out->values[i] = cols[i].values;
+        out->counts[i] = cols[i].counts;
+        out->offs[i] = cols[i].offs;
+        out->cap[i] = cols[i].capacity;
+        if (fd.kind == MRPDR_SCALAR) {
+            if (n && !cols[i].values) return fail("%s: field %d has no values buffer", who, i);
+        } else {
+            if (n && (!cols[i].counts || !cols[i].offs)) return fail("%s: field %d needs counts and offs", who, i);
+            if (need_values && !cols[i].values && cols[i].capacity)
+                return fail("%s: field %d has no values buffer", who, i);
+            if (((uintptr_t)cols[i].values & 15u) != 0)
+                return fail("%s: field %d values must be 16-byte aligned", who, i);
+        }
+    }
+    return 1;
+}
+
+static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *w, uint64_t n, WireDev *out)
+{
+    if (!w) return fail("%s: NULL wire", who);
+    if (n && !w->base) return fail("%s: NULL arena", who);
+    out->base = w->base; out->offsets = w->offsets; out->lens = w->lens;
+    out->stride = w->stride; out->bytes = w->bytes;
+    if (!w->lens && !f->fixed) return fail("%s: lens is required for variable-length formats", who);
+    if (!w->offsets) {
+        if (!f->fixed) return fail("%s: offsets are required for variable-length formats", who);
+        if (w->stride < f->dev.fixed_bytes)
+            return fail("%s: stride %llu is shorter than the packet (%u bytes)", who,
+                        (unsigned long long)w->stride, f->dev.fixed_bytes);
+        if (n && n * w->stride > w->bytes) return fail("%s: arena too small for %llu packets", who, (unsigned long long)n);
+    }
+    return 1;
+}
+
+// exclusive scan of in[n] (rounded up to align) into out[n+1]
+static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t align, uint64_t *out, hipStream_t st)
+{
+    const uint32_t tiles = n ? blocks_for(n, SCAN_TILE) : 1;
+    if (n) {
+        k_scan_partial<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, c->tile_sums);
+        LAUNCHED("k_scan_partial");
+        k_scan_top<<<1, MRPDR_TPB, 0, st>>>(c->tile_sums, tiles);
+        LAUNCHED("k_scan_top");
+    }
+    k_scan_final<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, c->tile_sums, out);
+    LAUNCHED("k_scan_final");
+    return 1;
+}
+
+static bool rows_path_ok(const mrpdr_fmt *f, const WireDev &w)
+{
+    return f->fixed && !w.offsets && w.stride <= ROWS_MAX_STRIDE && w.stride > 0 &&
+           ((uintptr_t)w.base & 15u) == 0;
+}
+
+// ---------------------------------------------------------------------------
+// sizing
+// ---------------------------------------------------------------------------
+extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                     uint64_t n, uint32_t align, uint64_t *lens, uint64_t *offsets,
+                                     uint64_t *total_host, void *stream)
+{
+    if (!check_common("mrpdr_wave_sizeof", c, f, n)) return 0;
+    if (align == 0 || align > 256 || (align & (align - 1))) return fail("mrpdr_wave_sizeof: align must be a power of two <= 256");
+    if (!offsets) return fail("mrpdr_wave_sizeof: NULL offsets");
+    hipStream_t st = (hipStream_t)stream;
+    if (f->fixed) {
+        const uint64_t len = f->dev.fixed_bytes;
+        const uint64_t stride = (len + align - 1) & ~(uint64_t)(align - 1);
+        k_offsets_fixed<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, st>>>(n, len, stride, lens, offsets);
+        LAUNCHED("k_offsets_fixed");
+        if (total_host) *total_host = n * stride;
+        return 1;
+    }
+    if (n && !lens) return fail("mrpdr_wave_sizeof: NULL lens");
+    ColsDev cd;
+    if (!fill_cols("mrpdr_wave_sizeof", f, cols, n, false, &cd)) return 0;
+    if (n) {
+        k_size<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, cd, n, lens);
+        LAUNCHED("k_size");
+    }
+    if (!run_scan(c, lens, n, align, offsets, st)) return 0;
+    if (total_host) {
+        HIP_OK(hipMemcpyAsync(total_host, offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// segment copies
+// ---------------------------------------------------------------------------
+template <int W, bool SWAP, bool ENCODE>
+static int32_t launch_copy(mrpdr_ctx *c, const CopyArgs &a, const FmtDev &fmt, const ColsDev &cd, hipStream_t st)
+{
+    // upper bound of the payload: it cannot exceed the arena or the column
+    uint64_t bound = a.wire.bytes < a.dense_cap ? a.wire.bytes : a.dense_cap;
+    uint64_t chunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
+    if (chunks == 0) return 1;
+    const uint64_t max_blocks = (uint64_t)c->num_cu * 8;
+    uint32_t grid = (uint32_t)(chunks < max_blocks ? chunks : max_blocks);
+    k_copy<W, SWAP, ENCODE><<<grid, MRPDR_TPB, 0, st>>>(a, fmt, cd);
+    LAUNCHED("k_copy");
+    return 1;
+}
+
+template <bool ENCODE>
+static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
+                          uint64_t n, bool swap, hipStream_t st)
+{
+    const FieldDev &fd = f->dev.f[field];
+    CopyArgs a;
+    a.wire = wd;
+    a.dense = (uint8_t *)cd.values[field];
+    a.seg_offs = cd.offs[field];
+    a.n = n;
+    a.dense_cap = cd.cap[field] * fd.width;
+    a.status = c->status;
+    a.field = field;
+    if (n == 0 || a.dense_cap == 0) return 1;
+    // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
+    const bool sw = swap && fd.width > 1 && !ENCODE;
+    switch (fd.width) {
+    case 1: return launch_copy<1, false, ENCODE>(c, a, f->dev, cd, st);
+    case 2: return sw ? launch_copy<2, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<2, false, ENCODE>(c, a, f->dev, cd, st);
+    case 4: return sw ? launch_copy<4, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<4, false, ENCODE>(c, a, f->dev, cd, st);
+    default: return sw ? launch_copy<8, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<8, false, ENCODE>(c, a, f->dev, cd, st);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------
+extern "C" int32_t mrpdr_wave_encode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                     uint64_t n, const mrpdr_wire *wire, void *stream)
+{
+    if (!check_common("mrpdr_wave_encode", c, f, n)) return 0;
+    ColsDev cd;
+    WireDev wd;
+    if (!fill_cols("mrpdr_wave_encode", f, cols, n, true, &cd)) return 0;
+    if (!fill_wire("mrpdr_wave_encode", f, wire, n, &wd)) return 0;
+    if (n == 0 || f->dev.nf == 0) return 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_path_ok(f, wd)) {
+        k_rows_encode<<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, ROWS_PER_BLOCK * wd.stride, st>>>(f->dev, wd, cd, n);
+        LAUNCHED("k_rows_encode");
+        return 1;
+    }
+    k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
+    LAUNCHED("k_walk_encode");
+    for (int i = 0; i < f->dev.nf; i++)
+        if (f->dev.f[i].kind != MRPDR_SCALAR)
+            if (!copy_field<true>(c, f, wd, cd, i, n, false, st)) return 0;
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------
+extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                           uint64_t n, int32_t sender_bo, mrpdr_column *cols,
+                                           int32_t *ok, uint64_t *totals_host, void *stream)
+{
+    if (!check_common("mrpdr_wave_decode_begin", c, f, n)) return 0;
+    if (sender_bo != MRPDR_LITTLEENDIAN && sender_bo != MRPDR_BIGENDIAN)
+        return fail("mrpdr_wave_decode_begin: bad byte order %d", sender_bo);
+    ColsDev cd;
+    WireDev wd;
+    if (!fill_cols("mrpdr_wave_decode_begin", f, cols, n, false, &cd)) return 0;
+    if (!fill_wire("mrpdr_wave_decode_begin", f, wire, n, &wd)) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
+    if (totals_host) memset(totals_host, 0, sizeof(uint64_t) * (size_t)f->dev.nf);
+    if (f->dev.nf == 0) return 1;
+    if (n) {
+        if (rows_path_ok(f, wd)) {
+            const size_t lds = ROWS_PER_BLOCK * wd.stride;
+            if (swap) k_rows_decode<true><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+            else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+            LAUNCHED("k_rows_decode");
+        } else {
+            if (swap) k_walk_decode<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok);
+            else      k_walk_decode<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok);
+            LAUNCHED("k_walk_decode");
+        }
+    }
+    if (f->fixed) return 1;
+    for (int i = 0; i < f->dev.nf; i++) {
+        if (f->dev.f[i].kind == MRPDR_SCALAR) continue;
+        if (!run_scan(c, cd.counts[i], n, 1, cd.offs[i], st)) return 0;
+        if (totals_host)
+            HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    }
+    if (totals_host) HIP_OK(hipStreamSynchronize(st));
+    return 1;
+}
+
+extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                            uint64_t n, int32_t sender_bo, mrpdr_column *cols, void *stream)
+{
+    if (!check_common("mrpdr_wave_decode_finish", c, f, n)) return 0;
+    if (f->fixed || n == 0) return 1;
+    ColsDev cd;
+    WireDev wd;
+    if (!fill_cols("mrpdr_wave_decode_finish", f, cols, n, true, &cd)) return 0;
+    if (!fill_wire("mrpdr_wave_decode_finish", f, wire, n, &wd)) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
+    for (int i = 0; i < f->dev.nf; i++)
+        if (f->dev.f[i].kind != MRPDR_SCALAR)
+            if (!copy_field<false>(c, f, wd, cd, i, n, swap, st)) return 0;
+    return 1;
+}
+
+extern "C" int32_t mrpdr_wave_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                     uint64_t n, int32_t sender_bo, mrpdr_column *cols,
+                                     int32_t *ok, void *stream)
+{
+    if (!mrpdr_wave_decode_begin(c, f, wire, n, sender_bo, cols, ok, nullptr, stream)) return 0;
+    return mrpdr_wave_decode_finish(c, f, wire, n, sender_bo, cols, stream);
+}
+
+// ---------------------------------------------------------------------------
+// headers
+// ---------------------------------------------------------------------------
+static int32_t make_image(const char *who, const mrpdr_fmt *f, HdrImage *img)
+{
+    if (!f) return fail("%s: NULL format", who);
+    size_t l = strlen(f->text) + 1;
+    if (l > HDR_MAX_FMT) return fail("%s: format string longer than %d bytes", who, HDR_MAX_FMT - 1);
+    memset(img, 0, sizeof *img);
+    img->fmt_bytes = (uint32_t)l;
+    memcpy(img->fmt, f->text, l);
+    return 1;
+}
+
+extern "C" uint64_t mrpdr_header_bytes(const mrpdr_fmt *f)
+{
+    return f ? 16 + strlen(f->text) + 1 + 8 + 1 : 0;     // src/Packet.C:557-593
+}
+
+extern "C" int32_t mrpdr_wave_encode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n,
+                                             uint32_t stream_id, const uint32_t *stream_ids,
+                                             int32_t tag, const int32_t *tags,
+                                             uint32_t src_rank, const uint32_t *src_ranks,
+                                             uint8_t *hdrs, uint64_t hdr_stride, void *stream)
+{
+    if (!c) return fail("mrpdr_wave_encode_headers: NULL ctx");
+    HdrImage img;
+    if (!make_image("mrpdr_wave_encode_headers", f, &img)) return 0;
+    if (hdr_stride < mrpdr_header_bytes(f)) return fail("mrpdr_wave_encode_headers: stride shorter than the header");
+    if (n == 0) return 1;
+    if (!hdrs) return fail("mrpdr_wave_encode_headers: NULL output");
+    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, hdrs, hdr_stride, n };
+    k_hdr_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
+    LAUNCHED("k_hdr_encode");
+    return 1;
+}
+
+extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n,
+                                             const uint8_t *hdrs, const uint64_t *hdr_offsets,
+                                             const uint64_t *hdr_lens, uint64_t hdr_stride,
+                                             uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
+                                             uint8_t *byteorders, uint64_t *ndests, int32_t *ok,
+                                             void *stream)
+{
+    if (!c) return fail("mrpdr_wave_decode_headers: NULL ctx");
+    HdrImage img;
+    if (!make_image("mrpdr_wave_decode_headers", f, &img)) return 0;
+    if (n == 0) return 1;
+    if (!hdrs) return fail("mrpdr_wave_decode_headers: NULL input");
+    HdrDecodeArgs a = { hdrs, hdr_offsets, hdr_lens, hdr_stride, stream_ids, tags, src_ranks,
+                        byteorders, ndests, ok, n };
+    k_hdr_decode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
+    LAUNCHED("k_hdr_decode");
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// filters
+// ---------------------------------------------------------------------------
+template <int OP, typename T>
+static int32_t run_filter(mrpdr_ctx *c, int32_t shape, const FilterIn &in, uint8_t *result,
+                          int32_t *result_ok, hipStream_t st)
+{
+    if (shape == MRPDR_SHAPE_FLAT) {
+        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok);
+        LAUNCHED("k_filter_flat");
+        return 1;
+    }
+    const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
+    if (tiles) {
+        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, c->partials);
+        LAUNCHED("k_filter_tree_tile");
+    }
+    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(c->partials, tiles, result, result_ok);
+    LAUNCHED("k_filter_tree_top");
+    return 1;
+}
+
+template <typename T>
+static int32_t run_filter_op(mrpdr_ctx *c, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
+                             int32_t *result_ok, hipStream_t st)
+{
+    switch (op) {
+    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(c, shape, in, result, result_ok, st);
+    }
+    return fail("mrpdr_wave_filter: unknown operator %d", op);
+}
+
+extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
+                                     const void *values, uint64_t value_stride,
+                                     const void *counts, uint64_t count_stride,
+                                     uint64_t n, int32_t swap,
+                                     void *result, int32_t *result_ok, void *stream)
+{
+    if (!c) return fail("mrpdr_wave_filter: NULL ctx");
+    if (n > c->max_packets) return fail("mrpdr_wave_filter: n exceeds the ctx limit");
+    if (!result) return fail("mrpdr_wave_filter: NULL result");
+    if (n && !values) return fail("mrpdr_wave_filter: NULL values");
+    if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
+    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
+    uint8_t *res = (uint8_t *)result;
+    hipStream_t st = (hipStream_t)stream;
+    switch (type) {
+    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_INT16_T:  return run_filter_op<int16_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_INT32_T:  return run_filter_op<int32_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_INT64_T:  return run_filter_op<int64_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_FLOAT_T:  return run_filter_op<float>(c, op, shape, in, res, result_ok, st);
+    case MRPDR_DOUBLE_T: return run_filter_op<double>(c, op, shape, in, res, result_ok, st);
+    }
+    // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
+    return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
+}

@@ -1,0 +1,179 @@
+// Scalars and length prefixes: packed rows <-> per-field columns.
+//
+// The reference handles these one primitive at a time: pdr_packet_data switches on
+// the element type (src/Packet.C:629-828) and calls pdr_<type>, which calls
+// pdrmem_put<type> / pdrmem_get<type>[ _swap ] (src/pdr.c:34-127,
+// src/pdr_mem.c:22-315) at a running cursor with a bounds check, no padding.
+//
+// Two forms here:
+//   k_rows_*   scalar-only formats in a packed arena: a workgroup stages 256 packet
+//              rows in LDS with 128-bit coalesced global accesses and transposes
+//              them to / from the columns
+//   k_walk_*   any format / any arena layout: one lane walks one packet
+#pragma once
+
+#include "common.h"
+
+#define ROWS_PER_BLOCK MRPDR_TPB
+#define ROWS_MAX_STRIDE 256
+
+// ---------------------------------------------------------------------------
+// sizing of variable-length packets (encode side): the pdr_sizeof dry run
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MRPDR_TPB) void k_size(FmtDev fmt, ColsDev cols, uint64_t n, uint64_t *lens)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= n) return;
+    uint64_t len = fmt.fixed_bytes;
+    for (int f = 0; f < fmt.nf; f++)
+        if (fmt.f[f].kind != MRPDR_SCALAR) len += cols.counts[f][i] * (uint64_t)fmt.f[f].width;
+    lens[i] = len;
+}
+
+// ---------------------------------------------------------------------------
+// LDS-staged transposition, scalar-only formats, packed arena
+// ---------------------------------------------------------------------------
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode(FmtDev fmt, WireDev wire, ColsDev cols,
+                                                           uint64_t n, int32_t *ok)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const uint32_t np = (uint32_t)((n - p0) < ROWS_PER_BLOCK ? (n - p0) : ROWS_PER_BLOCK);
+    const uint32_t stride = (uint32_t)wire.stride;
+    const uint32_t tile_bytes = np * stride;
+    // p0 * stride is a multiple of 256 bytes, so with a 16-byte aligned arena every
+    // 16-byte piece of the tile is an aligned 128-bit load.
+    const uint8_t *g = wire.base + p0 * (uint64_t)stride;
+    for (uint32_t off = threadIdx.x * 16u; off < tile_bytes; off += MRPDR_TPB * 16u) {
+        if (off + 16u <= tile_bytes) {
+            *reinterpret_cast<uint4 *>(tile + off) = *reinterpret_cast<const uint4 *>(g + off);
+        } else {
+            for (uint32_t b = off; b < tile_bytes; b++) tile[b] = g[b];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x >= np) return;
+    const uint64_t i = p0 + threadIdx.x;
+    const uint8_t *row = tile + threadIdx.x * stride;
+    const uint64_t len = wire.lens ? wire.lens[i] : (uint64_t)fmt.fixed_bytes;
+    bool good = true;
+    for (int f = 0; f < fmt.nf; f++) {
+        const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
+        uint64_t v = 0;
+        // same test as every pdrmem_get*: width > remaining space -> FALSE
+        if (good && (uint64_t)at + w <= len && at + w <= stride) {
+            for (uint32_t b = 0; b < w; b++) {
+                const uint32_t src = SWAP ? (w - 1 - b) : b;      // src/byte_order.c:12-16
+                v |= (uint64_t)row[at + src] << (8 * b);
+            }
+        } else {
+            good = false;
+        }
+        st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + i * w, (int)w, v);
+    }
+    if (ok) ok[i] = good ? 1 : 0;
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
+    const uint32_t np = (uint32_t)((n - p0) < ROWS_PER_BLOCK ? (n - p0) : ROWS_PER_BLOCK);
+    const uint32_t stride = (uint32_t)wire.stride;
+    const uint32_t tile_bytes = np * stride;
+    if (threadIdx.x < np) {
+        const uint64_t i = p0 + threadIdx.x;
+        uint8_t *row = tile + threadIdx.x * stride;
+        for (int f = 0; f < fmt.nf; f++) {
+            const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
+            const uint64_t v = ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + i * w, (int)w, false);
+            for (uint32_t b = 0; b < w; b++) row[at + b] = (uint8_t)(v >> (8 * b));
+        }
+        for (uint32_t b = fmt.fixed_bytes; b < stride; b++) row[b] = 0;     // arena padding
+    }
+    __syncthreads();
+    uint8_t *g = wire.base + p0 * (uint64_t)stride;
+    for (uint32_t off = threadIdx.x * 16u; off < tile_bytes; off += MRPDR_TPB * 16u) {
+        if (off + 16u <= tile_bytes) {
+            *reinterpret_cast<uint4 *>(g + off) = *reinterpret_cast<const uint4 *>(tile + off);
+        } else {
+            for (uint32_t b = off; b < tile_bytes; b++) g[b] = tile[b];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// generic walkers: one lane per packet
+// ---------------------------------------------------------------------------
+// Decode walk.  Scalars go to their columns, the element count of every array /
+// string field goes to counts[], ok[i] tells whether the whole packet decoded.
+// Failure rules are the reference's: a primitive wider than the remaining space
+// fails (src/pdr_mem.c:42,80,130,...), a count above the token's bound fails
+// (src/pdr.c:224,429), array elements are checked one by one so the array fails when
+// count*width exceeds the space (src/pdr.c:459-462).  After the first failure the
+// remaining fields of that packet read as zero.
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev wire, ColsDev cols,
+                                                           uint64_t n, int32_t *ok)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t at = pkt_off(wire, i);
+    uint64_t space = pkt_len(wire, fmt, i);
+    bool good = at <= wire.bytes && space <= wire.bytes - at;
+    const uint8_t *p = wire.base + at;
+    for (int f = 0; f < fmt.nf; f++) {
+        const FieldDev fd = fmt.f[f];
+        const uint32_t w = fd.width;
+        if (fd.kind == MRPDR_SCALAR) {
+            uint64_t v = 0;
+            if (good && w <= space) { v = ld_wire_w(p, (int)w, SWAP); p += w; space -= w; }
+            else good = false;
+            st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + i * w, (int)w, v);
+        } else if (fd.kind == MRPDR_ARRAY) {
+            uint64_t cnt = 0;
+            if (good && 8 <= space) {
+                cnt = ld_wire<8>(p, SWAP); p += 8; space -= 8;
+                const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
+                if (cnt > bound || cnt > space / w) { good = false; cnt = 0; }
+                p += cnt * w; space -= cnt * w;
+            } else good = false;
+            cols.counts[f][i] = cnt;
+        } else {    // MRPDR_STRING: u32 strlen+1, then the bytes, NUL included
+            uint64_t cnt = 0;
+            if (good && 4 <= space) {
+                cnt = ld_wire<4>(p, SWAP); p += 4; space -= 4;
+                if (cnt == 0 || cnt > space) { good = false; cnt = 0; }
+                p += cnt; space -= cnt;
+            } else good = false;
+            cols.counts[f][i] = cnt;
+        }
+    }
+    if (ok) ok[i] = good ? 1 : 0;
+}
+
+// Encode walk: scalars and length prefixes at their running cursor.  Array and
+// string payloads are moved by the segment copy kernel.
+__global__ __launch_bounds__(MRPDR_TPB) void k_walk_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= n) return;
+    uint8_t *p = wire.base + pkt_off(wire, i);
+    for (int f = 0; f < fmt.nf; f++) {
+        const FieldDev fd = fmt.f[f];
+        const uint32_t w = fd.width;
+        if (fd.kind == MRPDR_SCALAR) {
+            st_w(p, (int)w, ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + i * w, (int)w, false));
+            p += w;
+        } else if (fd.kind == MRPDR_ARRAY) {
+            const uint64_t cnt = cols.counts[f][i];
+            st_u<uint64_t>(p, cnt);                      // pdr_uint64(count), src/pdr.c:425
+            p += 8 + cnt * w;
+        } else {
+            const uint64_t cnt = cols.counts[f][i];
+            st_u<uint32_t>(p, (uint32_t)cnt);            // pdr_uint32(strlen+1), src/pdr.c:295-297
+            p += 4 + cnt;
+        }
+    }
+}

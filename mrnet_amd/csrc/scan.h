@@ -1,0 +1,111 @@
+// Exclusive prefix scan over per-packet lengths / element counts.
+//
+// This is the batched form of the reference's sizing pass: pdr_sizeof() walks one
+// packet to learn its length (src/pdr_sizeof.c:120-140) so that encode_pdr_data can
+// malloc it (src/Packet.C:61-69).  Here every lane sizes packets, a 64-lane wavefront
+// scan turns lengths into offsets, and three small launches stitch the workgroups
+// together (partial sums -> scan of the sums -> final offsets).
+#pragma once
+
+#include "common.h"
+
+#define SCAN_IPT 8                          // items per thread
+#define SCAN_TILE (MRPDR_TPB * SCAN_IPT)    // items per workgroup
+
+__device__ inline uint64_t round_up_pow2(uint64_t v, uint32_t align)
+{
+    return (v + (uint64_t)(align - 1)) & ~(uint64_t)(align - 1);
+}
+
+// Inclusive scan across the 64 lanes of a wavefront.
+__device__ inline uint64_t wave_inclusive_scan(uint64_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint64_t up = __shfl_up((unsigned long long)v, d, 64);
+        if (lane >= d) v += up;
+    }
+    return v;
+}
+
+// Workgroup-wide exclusive scan of one value per thread; *total = sum over the group.
+__device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *total)
+{
+    __shared__ uint64_t wave_sums[MRPDR_TPB / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = wave_inclusive_scan(v);
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    uint64_t base = 0, sum = 0;
+#pragma unroll
+    for (int w = 0; w < MRPDR_TPB / 64; w++) {
+        uint64_t s = wave_sums[w];
+        if (w < wave) base += s;
+        sum += s;
+    }
+    __syncthreads();
+    *total = sum;
+    return base + inc - v;
+}
+
+// Pass 1: sum of the (aligned) items of each tile.
+__global__ __launch_bounds__(MRPDR_TPB) void k_scan_partial(const uint64_t *in, uint64_t n,
+                                                            uint32_t align, uint64_t *tile_sums)
+{
+    const uint64_t first = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++)
+        if (first + k < n) s += round_up_pow2(in[first + k], align);
+    uint64_t total;
+    block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+// Pass 2: one workgroup turns the tile sums into exclusive prefixes, in place.
+__global__ __launch_bounds__(MRPDR_TPB) void k_scan_top(uint64_t *tile_sums, uint64_t ntiles)
+{
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < ntiles; base += MRPDR_TPB) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < ntiles ? tile_sums[i] : 0;
+        uint64_t total;
+        const uint64_t ex = block_exclusive_scan(v, &total);
+        if (i < ntiles) tile_sums[i] = carry + ex;
+        carry += total;
+    }
+}
+
+// Pass 3: offsets[i] = prefix of tile + scan inside the tile; offsets[n] = grand total.
+__global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, uint64_t n,
+                                                          uint32_t align, const uint64_t *tile_prefix,
+                                                          uint64_t *out)
+{
+    const uint64_t first = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
+    uint64_t v[SCAN_IPT];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) {
+        v[k] = first + k < n ? round_up_pow2(in[first + k], align) : 0;
+        s += v[k];
+    }
+    uint64_t total;
+    uint64_t run = tile_prefix[blockIdx.x] + block_exclusive_scan(s, &total);
+#pragma unroll
+    for (int k = 0; k < SCAN_IPT; k++) {
+        if (first + k < n) out[first + k] = run;
+        run += v[k];
+        if (first + k + 1 == n) out[n] = run;
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+// Packed layout of a fixed-length format: closed form, no scan needed.
+__global__ __launch_bounds__(MRPDR_TPB) void k_offsets_fixed(uint64_t n, uint64_t len, uint64_t stride,
+                                                             uint64_t *lens, uint64_t *offsets)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i < n && lens) lens[i] = len;
+    if (i <= n && offsets) offsets[i] = i * stride;
+}

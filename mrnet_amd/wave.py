@@ -1,0 +1,388 @@
+"""Host side of the wave codec: the reference's Packet / DataElement / filter surface,
+one wave (n packets of one format string) at a time, over the C ABI of include/mrpdr.h.
+
+PyTorch is plumbing only: device buffers, the current HIP stream, torch.distributed.
+All arithmetic and byte movement happens in the HIP kernels of mrnet_amd/csrc.
+
+Mirrors, for a wave instead of a packet:
+  Fmt2Type / DataType         src/DataElement.C:205-297, include/mrnet/DataElement.h:27-45
+  Packet ctor + encode        src/Packet.C:137-275, 54-85
+  Packet(hdr, buf) + decode   src/Packet.C:277-295, 87-133
+  Packet::unpack              src/Packet.C:329-353, 522-542 (returns -1 on a format mismatch)
+  tfilter_Sum/Max/Min/Avg     src/FilterDefinitions.C:90-645
+"""
+import ctypes as C
+import enum
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+class DataType(enum.IntEnum):
+    UNKNOWN_T = 0
+    CHAR_T = 1
+    UCHAR_T = 2
+    CHAR_ARRAY_T = 3
+    UCHAR_ARRAY_T = 4
+    STRING_T = 5
+    STRING_ARRAY_T = 6
+    INT16_T = 7
+    UINT16_T = 8
+    INT16_ARRAY_T = 9
+    UINT16_ARRAY_T = 10
+    INT32_T = 11
+    UINT32_T = 12
+    INT32_ARRAY_T = 13
+    UINT32_ARRAY_T = 14
+    INT64_T = 15
+    UINT64_T = 16
+    INT64_ARRAY_T = 17
+    UINT64_ARRAY_T = 18
+    FLOAT_T = 19
+    DOUBLE_T = 20
+    FLOAT_ARRAY_T = 21
+    DOUBLE_ARRAY_T = 22
+    CHAR_LRG_ARRAY_T = 23
+    UCHAR_LRG_ARRAY_T = 24
+    STRING_LRG_ARRAY_T = 25
+    INT16_LRG_ARRAY_T = 26
+    UINT16_LRG_ARRAY_T = 27
+    INT32_LRG_ARRAY_T = 28
+    UINT32_LRG_ARRAY_T = 29
+    INT64_LRG_ARRAY_T = 30
+    UINT64_LRG_ARRAY_T = 31
+    FLOAT_LRG_ARRAY_T = 32
+    DOUBLE_LRG_ARRAY_T = 33
+
+
+LITTLEENDIAN, BIGENDIAN = 0, 1
+SCALAR, ARRAY, STRING, STRING_ARRAY = 0, 1, 2, 3
+TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3
+SHAPE_FLAT, SHAPE_TREE = 0, 1
+TREE_FANINS = (4, 2, 2, 2, 2, 2, 2, 4, 0)
+
+USER_STRM_BASE_ID = (1 << 30) + 10      # src/Stream.C:31-42
+FIRST_APPLICATION_TAG = 100             # include/mrnet/Types.h:20
+UNKNOWN_RANK = 0xFFFFFFFF               # include/mrnet/Types.h (UnknownRank)
+
+# device storage: torch has no arithmetic on unsigned >8 bit, so unsigned columns are
+# held in the signed dtype of the same width (same bits)
+_STORE = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+_NP_ELEM = {
+    "c": np.int8, "uc": np.uint8, "hd": np.int16, "uhd": np.uint16, "d": np.int32, "ud": np.uint32,
+    "ld": np.int64, "uld": np.uint64, "f": np.float32, "lf": np.float64, "s": np.uint8,
+}
+
+
+class PdrError(RuntimeError):
+    """A C-ABI call returned FALSE (the reference would raise ERR_PACKING)."""
+
+
+def _check(ok, what):
+    if not ok:
+        raise PdrError("%s: %s" % (what, capi.last_error()))
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Format:
+    """A compiled format string (tokenised once, not once per packet)."""
+
+    def __init__(self, fmt):
+        self._lib = capi.load()
+        self.text = fmt
+        self.handle = self._lib.mrpdr_fmt_compile(fmt.encode())
+        if not self.handle:
+            raise ValueError(capi.last_error())
+        n = self._lib.mrpdr_fmt_nfields(self.handle)
+        self.types = [DataType(self._lib.mrpdr_fmt_field_type(self.handle, i)) for i in range(n)]
+        self.kinds = [self._lib.mrpdr_fmt_field_kind(self.handle, i) for i in range(n)]
+        self.widths = [self._lib.mrpdr_fmt_field_width(self.handle, i) for i in range(n)]
+        self.is_fixed = bool(self._lib.mrpdr_fmt_is_fixed(self.handle))
+        self.fixed_bytes = int(self._lib.mrpdr_fmt_fixed_bytes(self.handle))
+        self.header_bytes = int(self._lib.mrpdr_header_bytes(self.handle))
+        self.tokens = [t for t in fmt.replace("%", " ").split()]
+
+    def __len__(self):
+        return len(self.types)
+
+    def np_dtype(self, i):
+        tok = self.tokens[i]
+        tok = tok[1:] if tok[0] in "aA" else tok
+        return np.dtype(_NP_ELEM[tok])
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.mrpdr_fmt_free(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def Fmt2Type(token):
+    """DataType of one format token, e.g. Fmt2Type('uld') (src/DataElement.C:205-297)."""
+    try:
+        f = Format("%" + token)
+    except ValueError:
+        return DataType.UNKNOWN_T
+    return f.types[0] if len(f) == 1 else DataType.UNKNOWN_T
+
+
+class Column:
+    """One decoded field of a wave on the device (struct mrpdr_column)."""
+
+    def __init__(self, values=None, counts=None, offs=None, capacity=None):
+        self.values, self.counts, self.offs = values, counts, offs
+        self.capacity = capacity if capacity is not None else (0 if values is None else values.numel())
+
+    def c_struct(self):
+        return capi.Column(_ptr(self.values), _ptr(self.counts), _ptr(self.offs), self.capacity)
+
+
+class WireWave:
+    """Encoded data buffers of a wave: arena + offsets/lens, or a packed stride."""
+
+    def __init__(self, arena, n, offsets=None, lens=None, stride=0):
+        self.arena, self.n, self.offsets, self.lens, self.stride = arena, n, offsets, lens, stride
+
+    def c_struct(self):
+        return capi.Wire(_ptr(self.arena), _ptr(self.offsets), _ptr(self.lens), self.stride,
+                         self.arena.numel())
+
+    def packet_bytes(self, i):
+        """Bytes of packet i as numpy (test / legacy-boundary helper: copies to the host)."""
+        if self.offsets is not None:
+            a = int(self.offsets[i].item())
+        else:
+            a = i * self.stride
+        ln = int(self.lens[i].item()) if self.lens is not None else None
+        return self.arena[a:a + ln].cpu().numpy() if ln is not None else self.arena[a:a + self.stride].cpu().numpy()
+
+
+def _c_columns(cols):
+    arr = (capi.Column * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i] = c.c_struct()
+    return arr
+
+
+class Codec:
+    """A device context plus the wave operations (one per calling thread / stream)."""
+
+    def __init__(self, device=None, max_packets=1 << 21):
+        self._lib = capi.load()
+        if not torch.cuda.is_available():
+            raise PdrError("mrnet_amd needs a HIP device; there is no CPU fallback")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.max_packets = max_packets
+        self.handle = self._lib.mrpdr_ctx_create(self.device.index, max_packets)
+        _check(self.handle, "mrpdr_ctx_create")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self._lib.mrpdr_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- buffers ---------------------------------------------------------------
+    def empty(self, n, dtype):
+        return torch.empty(int(n), dtype=dtype, device=self.device)
+
+    def to_device(self, a):
+        """numpy -> device tensor holding the same bytes (unsigned kept as signed)."""
+        a = np.ascontiguousarray(a)
+        if a.dtype.kind == "u" and a.dtype.itemsize > 1:
+            a = a.view(np.dtype("i%d" % a.dtype.itemsize))
+        return torch.from_numpy(a).to(self.device)
+
+    @staticmethod
+    def to_numpy(t, dtype=None):
+        a = t.detach().cpu().numpy()
+        return a if dtype is None else a.view(dtype)
+
+    def columns_from_numpy(self, fmt, cols):
+        """cols: per field either a numpy array (scalar) or (counts, values) for arrays and
+        strings (string values hold every string's bytes NUL included)."""
+        out = []
+        for i, k in enumerate(fmt.kinds):
+            if k == SCALAR:
+                out.append(Column(self.to_device(np.asarray(cols[i], dtype=fmt.np_dtype(i)))))
+            else:
+                counts, values = cols[i]
+                counts = np.asarray(counts, dtype=np.uint64)
+                offs = np.zeros(len(counts) + 1, dtype=np.uint64)
+                np.cumsum(counts, out=offs[1:])
+                values = np.asarray(values, dtype=fmt.np_dtype(i))
+                out.append(Column(self.to_device(values), self.to_device(counts), self.to_device(offs),
+                                  capacity=values.size))
+        return out
+
+    def alloc_columns(self, fmt, n, capacities=None):
+        out = []
+        for i, k in enumerate(fmt.kinds):
+            w = fmt.widths[i]
+            if k == SCALAR:
+                out.append(Column(self.empty(n, _STORE[w])))
+            else:
+                cap = int(capacities[i]) if capacities is not None else 0
+                vals = self.empty(max(cap, 1), _STORE[w]) if cap else None
+                out.append(Column(vals, self.empty(n, torch.int64), self.empty(n + 1, torch.int64), cap))
+        return out
+
+    # ---- sizing (pdr_sizeof over the wave) ---------------------------------------
+    def sizeof(self, fmt, cols, n, align=1, want_total=True):
+        lens = self.empty(n, torch.int64)
+        offsets = self.empty(n + 1, torch.int64)
+        total = C.c_uint64(0)
+        ok = self._lib.mrpdr_wave_sizeof(self.handle, fmt.handle, _c_columns(cols), n, align,
+                                         _ptr(lens), _ptr(offsets),
+                                         C.byref(total) if want_total else None, _stream())
+        _check(ok, "mrpdr_wave_sizeof")
+        return lens, offsets, (total.value if want_total else None)
+
+    # ---- encode ---------------------------------------------------------------------
+    def encode_into(self, fmt, cols, wire):
+        w = wire.c_struct()
+        ok = self._lib.mrpdr_wave_encode(self.handle, fmt.handle, _c_columns(cols), wire.n,
+                                         C.byref(w), _stream())
+        _check(ok, "mrpdr_wave_encode")
+
+    def encode(self, fmt, cols, n, align=1, packed=None):
+        """Encode a wave.  Fixed formats default to the packed layout (no offsets array)."""
+        if packed is None:
+            packed = fmt.is_fixed
+        if packed:
+            if not fmt.is_fixed:
+                raise PdrError("packed layout needs a scalar-only format")
+            stride = (fmt.fixed_bytes + align - 1) // align * align
+            wire = WireWave(torch.zeros(max(n * stride, 1), dtype=torch.uint8, device=self.device),
+                            n, None, None, stride)
+        else:
+            lens, offsets, total = self.sizeof(fmt, cols, n, align)
+            wire = WireWave(torch.zeros(max(total, 1), dtype=torch.uint8, device=self.device),
+                            n, offsets, lens, 0)
+        self.encode_into(fmt, cols, wire)
+        return wire
+
+    # ---- decode ---------------------------------------------------------------------
+    def decode_begin(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN, want_totals=True):
+        w = wire.c_struct()
+        totals = (C.c_uint64 * max(1, len(fmt)))()
+        carr = _c_columns(cols)
+        r = self._lib.mrpdr_wave_decode_begin(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
+                                              carr, _ptr(ok), totals if want_totals else None, _stream())
+        _check(r, "mrpdr_wave_decode_begin")
+        return [totals[i] for i in range(len(fmt))] if want_totals else None
+
+    def decode_finish(self, fmt, wire, cols, sender_bo=LITTLEENDIAN):
+        w = wire.c_struct()
+        r = self._lib.mrpdr_wave_decode_finish(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
+                                               _c_columns(cols), _stream())
+        _check(r, "mrpdr_wave_decode_finish")
+
+    def decode_into(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN):
+        """Columns already sized by the caller: no host synchronisation."""
+        w = wire.c_struct()
+        r = self._lib.mrpdr_wave_decode(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
+                                        _c_columns(cols), _ptr(ok), _stream())
+        _check(r, "mrpdr_wave_decode")
+
+    def decode(self, fmt, wire, sender_bo=LITTLEENDIAN):
+        """Decode a wave; returns (columns, ok).  Array columns are allocated from the
+        totals the walk reports, so this synchronises once for variable formats."""
+        n = wire.n
+        cols = self.alloc_columns(fmt, n)
+        ok = self.empty(n, torch.int32)
+        totals = self.decode_begin(fmt, wire, cols, ok, sender_bo, want_totals=not fmt.is_fixed)
+        if not fmt.is_fixed:
+            for i, k in enumerate(fmt.kinds):
+                if k != SCALAR:
+                    cols[i].capacity = int(totals[i])
+                    cols[i].values = self.empty(max(int(totals[i]), 1), _STORE[fmt.widths[i]])
+            self.decode_finish(fmt, wire, cols, sender_bo)
+        return cols, ok
+
+    def status(self):
+        s = C.c_uint32(0)
+        _check(self._lib.mrpdr_ctx_status(self.handle, _stream(), C.byref(s)), "mrpdr_ctx_status")
+        return s.value
+
+    # ---- headers ---------------------------------------------------------------------
+    def encode_headers(self, fmt, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
+                       src_rank=UNKNOWN_RANK, stream_ids=None, tags=None, src_ranks=None,
+                       stride=None):
+        stride = fmt.header_bytes if stride is None else stride
+        hdrs = torch.zeros(max(n * stride, 1), dtype=torch.uint8, device=self.device)
+        r = self._lib.mrpdr_wave_encode_headers(self.handle, fmt.handle, n, stream_id, _ptr(stream_ids),
+                                                tag, _ptr(tags), src_rank, _ptr(src_ranks),
+                                                _ptr(hdrs), stride, _stream())
+        _check(r, "mrpdr_wave_encode_headers")
+        return hdrs, stride
+
+    def decode_headers(self, fmt, n, hdrs, stride=0, offsets=None, lens=None):
+        out = {
+            "stream_id": self.empty(n, torch.int32), "tag": self.empty(n, torch.int32),
+            "src_rank": self.empty(n, torch.int32), "byteorder": self.empty(n, torch.uint8),
+            "ndest": self.empty(n, torch.int64), "ok": self.empty(n, torch.int32),
+        }
+        r = self._lib.mrpdr_wave_decode_headers(self.handle, fmt.handle, n, _ptr(hdrs), _ptr(offsets),
+                                                _ptr(lens), stride, _ptr(out["stream_id"]),
+                                                _ptr(out["tag"]), _ptr(out["src_rank"]),
+                                                _ptr(out["byteorder"]), _ptr(out["ndest"]),
+                                                _ptr(out["ok"]), _stream())
+        _check(r, "mrpdr_wave_decode_headers")
+        return out
+
+    # ---- filters -----------------------------------------------------------------------
+    def filter_raw(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,
+                   shape=SHAPE_TREE, result=None, result_ok=None):
+        if result is None:
+            result = self.empty(16, torch.uint8)
+        if result_ok is None:
+            result_ok = self.empty(1, torch.int32)
+        r = self._lib.mrpdr_wave_filter(self.handle, op, int(dtype), shape, values_ptr, value_stride,
+                                        counts_ptr, count_stride, n, swap, _ptr(result),
+                                        _ptr(result_ok), _stream())
+        _check(r, "mrpdr_wave_filter")
+        return result, result_ok
+
+    def filter_columns(self, op, dtype, values, counts=None, shape=SHAPE_TREE):
+        """Filter over decoded columns: values = T[n] tensor, counts = int32[n] (AVG)."""
+        n = values.numel()
+        return self.filter_raw(op, dtype, _ptr(values), values.element_size(),
+                               _ptr(counts), 4, n, 0, shape)
+
+    def filter_wire(self, op, fmt, wire, sender_bo=LITTLEENDIAN, shape=SHAPE_TREE):
+        """Fused decode + filter straight on the wire bytes of a packed fixed-format wave
+        ('%T' for SUM/MIN/MAX, '%T %d' for AVG, as the built-in filters require)."""
+        want = 2 if op == TFILTER_AVG else 1
+        if len(fmt) != want or not fmt.is_fixed or (want == 2 and fmt.types[1] != DataType.INT32_T):
+            raise PdrError("filter format must be '%T'" + (" %d'" if want == 2 else "'"))
+        if wire.offsets is not None:
+            raise PdrError("filter_wire needs the packed layout")
+        base = wire.arena.data_ptr()
+        w = fmt.widths[0]
+        return self.filter_raw(op, fmt.types[0], base, wire.stride, base + w, wire.stride, wire.n,
+                               int(sender_bo != LITTLEENDIAN), shape)
+
+
+def result_value(result, result_ok, fmt_or_dtype, op):
+    """Host view of a filter result: (value, count or None), or None when absent."""
+    if int(result_ok.item()) == 0:
+        return None
+    raw = result.cpu().numpy()
+    dt = fmt_or_dtype if isinstance(fmt_or_dtype, np.dtype) else np.dtype(fmt_or_dtype)
+    v = raw[:dt.itemsize].view(dt)[0]
+    c = int(raw[dt.itemsize:dt.itemsize + 4].view(np.int32)[0]) if op == TFILTER_AVG else None
+    return v, c

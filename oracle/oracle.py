@@ -1,0 +1,272 @@
+"""ctypes front end of the CPU oracle (oracle/libpdr_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg; the product package never imports it.
+
+A wave is described by numpy columns, one dict per format token:
+    scalar        {"type": t, "values": T[n]}
+    array/string  {"type": t, "counts": u64[n], "offs": u64[n+1], "values": packed}
+                  (a string counts strlen+1 bytes, NUL included)
+    string array  adds "sub_counts": u64[S], "sub_offs": u64[S+1]; "values" = bytes
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libpdr_oracle.so")
+
+# include/mrnet/DataElement.h:27-45
+(UNKNOWN_T, CHAR_T, UCHAR_T, CHAR_ARRAY_T, UCHAR_ARRAY_T, STRING_T, STRING_ARRAY_T,
+ INT16_T, UINT16_T, INT16_ARRAY_T, UINT16_ARRAY_T, INT32_T, UINT32_T, INT32_ARRAY_T,
+ UINT32_ARRAY_T, INT64_T, UINT64_T, INT64_ARRAY_T, UINT64_ARRAY_T, FLOAT_T, DOUBLE_T,
+ FLOAT_ARRAY_T, DOUBLE_ARRAY_T, CHAR_LRG_ARRAY_T, UCHAR_LRG_ARRAY_T, STRING_LRG_ARRAY_T,
+ INT16_LRG_ARRAY_T, UINT16_LRG_ARRAY_T, INT32_LRG_ARRAY_T, UINT32_LRG_ARRAY_T,
+ INT64_LRG_ARRAY_T, UINT64_LRG_ARRAY_T, FLOAT_LRG_ARRAY_T, DOUBLE_LRG_ARRAY_T) = range(34)
+
+SUM, MIN, MAX, AVG = 0, 1, 2, 3
+LITTLE, BIG = 0, 1
+
+_ELEM_DTYPE = {
+    CHAR_T: np.int8, UCHAR_T: np.uint8, INT16_T: np.int16, UINT16_T: np.uint16,
+    INT32_T: np.int32, UINT32_T: np.uint32, INT64_T: np.int64, UINT64_T: np.uint64,
+    FLOAT_T: np.float32, DOUBLE_T: np.float64,
+    CHAR_ARRAY_T: np.int8, UCHAR_ARRAY_T: np.uint8, INT16_ARRAY_T: np.int16,
+    UINT16_ARRAY_T: np.uint16, INT32_ARRAY_T: np.int32, UINT32_ARRAY_T: np.uint32,
+    INT64_ARRAY_T: np.int64, UINT64_ARRAY_T: np.uint64, FLOAT_ARRAY_T: np.float32,
+    DOUBLE_ARRAY_T: np.float64,
+    CHAR_LRG_ARRAY_T: np.int8, UCHAR_LRG_ARRAY_T: np.uint8, INT16_LRG_ARRAY_T: np.int16,
+    UINT16_LRG_ARRAY_T: np.uint16, INT32_LRG_ARRAY_T: np.int32, UINT32_LRG_ARRAY_T: np.uint32,
+    INT64_LRG_ARRAY_T: np.int64, UINT64_LRG_ARRAY_T: np.uint64, FLOAT_LRG_ARRAY_T: np.float32,
+    DOUBLE_LRG_ARRAY_T: np.float64,
+    STRING_T: np.uint8, STRING_ARRAY_T: np.uint8, STRING_LRG_ARRAY_T: np.uint8,
+}
+
+
+class _Column(C.Structure):
+    _fields_ = [("type", C.c_int), ("values", C.c_void_p), ("counts", C.c_void_p),
+                ("offs", C.c_void_p), ("sub_counts", C.c_void_p), ("sub_offs", C.c_void_p)]
+
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the oracle with its Makefile (gcc); building the checker is not using it."""
+    if force or not os.path.exists(_LIB_PATH) or \
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "pdr_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        u64p, i32p, vp = C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_void_p
+        L.orc_fmt_types.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.c_int]
+        L.orc_fmt_types.restype = C.c_int
+        L.orc_type_width.argtypes = [C.c_int]; L.orc_type_width.restype = C.c_int
+        L.orc_type_kind.argtypes = [C.c_int]; L.orc_type_kind.restype = C.c_int
+        L.orc_local_bo.restype = C.c_int
+        L.orc_wave_sizeof.argtypes = [C.c_char_p, C.POINTER(_Column), C.c_uint64, vp]
+        L.orc_wave_sizeof.restype = C.c_int32
+        L.orc_wave_encode.argtypes = [C.c_char_p, C.POINTER(_Column), C.c_uint64, vp, vp, vp]
+        L.orc_wave_encode.restype = C.c_int32
+        L.orc_wave_decode.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_int,
+                                      C.POINTER(_Column), vp]
+        L.orc_wave_decode.restype = C.c_uint64
+        L.orc_header_encode.argtypes = [C.c_uint32, C.c_int32, C.c_uint32, C.c_char_p, vp,
+                                        C.c_uint64, vp, C.c_uint64]
+        L.orc_header_encode.restype = C.c_uint64
+        L.orc_header_decode.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), i32p,
+                                        C.POINTER(C.c_uint32), C.c_char_p, C.c_uint64, vp,
+                                        C.c_uint64, u64p, C.POINTER(C.c_int)]
+        L.orc_header_decode.restype = C.c_int32
+        L.orc_filter_flat.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp, i32p]
+        L.orc_filter_flat.restype = C.c_int32
+        L.orc_filter_tree.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp, C.c_int, vp, i32p]
+        L.orc_filter_tree.restype = C.c_int32
+        L.orc_byte_swap.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+        L.orc_byte_swap.restype = None
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def fmt_types(fmt):
+    buf = (C.c_int * 64)()
+    n = lib().orc_fmt_types(fmt.encode(), buf, 64)
+    if n < 0:
+        raise ValueError("unknown token in format %r" % fmt)
+    return [buf[i] for i in range(n)]
+
+
+def type_kind(t):
+    return lib().orc_type_kind(t)
+
+
+def type_width(t):
+    return lib().orc_type_width(t)
+
+
+def elem_dtype(t):
+    return np.dtype(_ELEM_DTYPE[t])
+
+
+def local_byteorder():
+    return lib().orc_local_bo()
+
+
+def _c_columns(cols, keep):
+    arr = (_Column * max(1, len(cols)))()
+    for i, c in enumerate(cols):
+        arr[i].type = c["type"]
+        for key in ("values", "counts", "offs", "sub_counts", "sub_offs"):
+            a = c.get(key)
+            if a is not None:
+                a = np.ascontiguousarray(a)
+                if key != "values":
+                    assert a.dtype == np.uint64, key
+                c[key] = a
+                keep.append(a)
+                setattr(arr[i], key, a.ctypes.data)
+    return arr
+
+
+def wave_sizeof(fmt, cols, n):
+    keep = []
+    lens = np.zeros(n, dtype=np.uint64)
+    ok = lib().orc_wave_sizeof(fmt.encode(), _c_columns(cols, keep), n, _ptr(lens))
+    if not ok:
+        raise RuntimeError("orc_wave_sizeof failed")
+    return lens
+
+
+def scan_offsets(lens, align=1):
+    """Exclusive scan of lens rounded up to `align` (the arena layout rule)."""
+    a = np.uint64(align)
+    padded = (lens.astype(np.uint64) + (a - np.uint64(1))) // a * a
+    offs = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(padded, out=offs[1:])
+    return offs
+
+
+def wave_encode(fmt, cols, n, align=1):
+    """Returns (arena u8[], offsets u64[n+1], lens u64[n]); padding bytes are zero."""
+    lens = wave_sizeof(fmt, cols, n)
+    offs = scan_offsets(lens, align)
+    arena = np.zeros(int(offs[-1]), dtype=np.uint8)
+    keep = []
+    lens2 = np.zeros(n, dtype=np.uint64)
+    ok = lib().orc_wave_encode(fmt.encode(), _c_columns(cols, keep), n, _ptr(offs),
+                               _ptr(arena), _ptr(lens2))
+    if not ok:
+        raise RuntimeError("orc_wave_encode failed")
+    assert np.array_equal(lens, lens2)
+    return arena, offs, lens
+
+
+def wave_decode(fmt, arena, offsets, lens, sender_bo=LITTLE):
+    """Returns (cols, ok i32[n]).  Columns are trimmed to the decoded totals."""
+    types = fmt_types(fmt)
+    n = len(lens)
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    lens = np.ascontiguousarray(lens, dtype=np.uint64)
+    cap = int(arena.size)
+    cols = []
+    for t in types:
+        k = type_kind(t)
+        c = {"type": t}
+        dt = elem_dtype(t)
+        if k == 0:
+            c["values"] = np.zeros(n, dtype=dt)
+        else:
+            c["counts"] = np.zeros(n, dtype=np.uint64)
+            c["offs"] = np.zeros(n + 1, dtype=np.uint64)
+            c["values"] = np.zeros(cap // dt.itemsize + 1, dtype=dt)
+            if k == 3:
+                c["sub_counts"] = np.zeros(cap + 1, dtype=np.uint64)
+                c["sub_offs"] = np.zeros(cap + 2, dtype=np.uint64)
+        cols.append(c)
+    ok = np.zeros(n, dtype=np.int32)
+    keep = []
+    lib().orc_wave_decode(fmt.encode(), _ptr(arena), _ptr(offsets), _ptr(lens), n, sender_bo,
+                          _c_columns(cols, keep), _ptr(ok))
+    for c in cols:
+        k = type_kind(c["type"])
+        if k in (1, 2):
+            c["values"] = c["values"][: int(c["offs"][n])].copy()
+        elif k == 3:
+            s = int(c["offs"][n])
+            c["sub_counts"] = c["sub_counts"][:s].copy()
+            c["sub_offs"] = c["sub_offs"][: s + 1].copy()
+            c["values"] = c["values"][: int(c["sub_offs"][s])].copy()
+    return cols, ok
+
+
+def header_encode(stream_id, tag, src_rank, fmt, dest=()):
+    dest = np.asarray(dest, dtype=np.uint32)
+    out = np.zeros(64 + len(fmt) + 4 * len(dest), dtype=np.uint8)
+    n = lib().orc_header_encode(stream_id, tag, src_rank, fmt.encode(), _ptr(dest), len(dest),
+                                _ptr(out), out.size)
+    if n == 0:
+        raise RuntimeError("orc_header_encode failed")
+    return out[:n].copy()
+
+
+def header_decode(hdr):
+    hdr = np.ascontiguousarray(hdr, dtype=np.uint8)
+    sid, tag, src = C.c_uint32(), C.c_int32(), C.c_uint32()
+    fmt = C.create_string_buffer(4096)
+    dest = np.zeros(max(1, hdr.size // 4), dtype=np.uint32)
+    nd, bo = C.c_uint64(), C.c_int()
+    ok = lib().orc_header_decode(_ptr(hdr), hdr.size, C.byref(sid), C.byref(tag), C.byref(src),
+                                 fmt, 4096, _ptr(dest), dest.size, C.byref(nd), C.byref(bo))
+    if not ok:
+        return None
+    return {"stream_id": sid.value, "tag": tag.value, "src_rank": src.value,
+            "fmt": fmt.value.decode(), "dest": dest[: nd.value].copy(), "byteorder": bo.value}
+
+
+def byte_swap(a, elsize):
+    """src/byte_order.c:8-17 over a whole buffer."""
+    a = np.ascontiguousarray(a).view(np.uint8)
+    out = np.empty_like(a)
+    assert a.size % elsize == 0
+    lib().orc_byte_swap(_ptr(out), _ptr(a), a.size // elsize, elsize)
+    return out
+
+
+def filter_flat(op, t, vals, cnt=None):
+    vals = np.ascontiguousarray(vals, dtype=elem_dtype(t))
+    if cnt is not None:
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    out = np.zeros(1, dtype=elem_dtype(t))
+    oc = C.c_int32(0)
+    ok = lib().orc_filter_flat(op, t, _ptr(vals), _ptr(cnt), vals.size, _ptr(out), C.byref(oc))
+    if not ok:
+        return None
+    return out[0], oc.value
+
+
+def filter_tree(op, t, vals, cnt, fanin):
+    vals = np.ascontiguousarray(vals, dtype=elem_dtype(t))
+    if cnt is not None:
+        cnt = np.ascontiguousarray(cnt, dtype=np.int32)
+    fan = np.ascontiguousarray(fanin, dtype=np.uint32)
+    out = np.zeros(1, dtype=elem_dtype(t))
+    oc = C.c_int32(0)
+    ok = lib().orc_filter_tree(op, t, _ptr(vals), _ptr(cnt), vals.size, _ptr(fan), fan.size,
+                               _ptr(out), C.byref(oc))
+    if not ok:
+        return None
+    return out[0], oc.value

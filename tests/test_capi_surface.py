@@ -1,0 +1,91 @@
+"""CPU-only checks of the drop-in boundary: the library loads, exports every symbol the
+header declares, its host-side format compiler agrees with the oracle, and compute
+entry points fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from wavegen import O, ROOT
+
+from mrnet_amd import capi
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "mrpdr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrpdr_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = capi.load()
+    declared = header_symbols()
+    assert declared, "no declarations found in include/mrpdr.h"
+    for name in declared:
+        assert hasattr(lib, name), "libmrpdr.so does not export %s" % name
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS is out of step with include/mrpdr.h"
+    assert lib.mrpdr_version().startswith(b"mrpdr")
+    assert lib.mrpdr_local_byteorder() == 0
+
+
+def test_no_torch_types_in_the_abi():
+    text = open(os.path.join(ROOT, "include", "mrpdr.h")).read()
+    assert 'extern "C"' in text
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)        # declarations only
+    assert "torch" not in text and "at::" not in text and "std::" not in text
+
+
+FORMATS = ["%d", "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s", "%d %uld %lf %s %auc", "%af",
+           "%lf %d", "%ad %ad %alf", "%Ac %Auc %Ahd %Auhd %Ad %Aud %Ald %Auld %Af %Alf",
+           "%d\t%d\n%d%d", ""]
+
+
+@pytest.mark.parametrize("fmt", FORMATS)
+def test_format_compiler_matches_oracle(fmt):
+    lib = capi.load()
+    h = lib.mrpdr_fmt_compile(fmt.encode())
+    assert h, capi.last_error()
+    types = O.fmt_types(fmt)
+    assert lib.mrpdr_fmt_nfields(h) == len(types)
+    fixed = 0
+    for i, t in enumerate(types):
+        assert lib.mrpdr_fmt_field_type(h, i) == t
+        assert lib.mrpdr_fmt_field_kind(h, i) == O.type_kind(t)
+        assert lib.mrpdr_fmt_field_width(h, i) == O.type_width(t)
+        fixed += {0: O.type_width(t), 1: 8, 2: 4}[O.type_kind(t)]
+    assert lib.mrpdr_fmt_fixed_bytes(h) == fixed
+    assert lib.mrpdr_fmt_is_fixed(h) == int(all(O.type_kind(t) == 0 for t in types))
+    assert lib.mrpdr_fmt_string(h) == fmt.encode()
+    # header length rule: 16 + strlen(fmt)+1 + 8 + 1 (src/Packet.C:557-593)
+    assert lib.mrpdr_header_bytes(h) == len(O.header_encode(1, 2, 3, fmt))
+    lib.mrpdr_fmt_free(h)
+
+
+@pytest.mark.parametrize("fmt", ["%q", "%lld", "%d %x", "%" + "d %" * 40 + "d"])
+def test_format_compiler_rejects(fmt):
+    lib = capi.load()
+    assert not lib.mrpdr_fmt_compile(fmt.encode())
+    assert capi.last_error()
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    lib = capi.load()
+    assert not lib.mrpdr_ctx_create(0, 1024)
+    assert "HIP device" in capi.last_error()
+    from mrnet_amd.wave import Codec, PdrError
+    with pytest.raises(PdrError):
+        Codec()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "mrnet_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".hpp", ".cc", ".cpp")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "pdr_oracle" not in text and "oracle." not in text and "import oracle" not in text, \
+                    "%s refers to the oracle" % fn

@@ -1,0 +1,311 @@
+"""Parity of the HIP codec with the oracle, through the C ABI, on seeded waves.
+Bar: bit-exact (byte and index work)."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O, columns_equal, make_wave, to_sender_order
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+
+
+def dev_cols(codec, fmt, ocols):
+    out = []
+    for k, c in zip(fmt.kinds, ocols):
+        if k == W.SCALAR:
+            out.append(W.Column(codec.to_device(c["values"])))
+        else:
+            vals = c["values"]
+            out.append(W.Column(codec.to_device(vals) if vals.size else codec.empty(1, torch.int8),
+                                codec.to_device(c["counts"]), codec.to_device(c["offs"]),
+                                capacity=vals.size))
+    return out
+
+
+def host_cols(fmt, dcols, n):
+    out = []
+    for i, (k, c) in enumerate(zip(fmt.kinds, dcols)):
+        dt = fmt.np_dtype(i)
+        d = {"type": int(fmt.types[i])}
+        if k == W.SCALAR:
+            d["values"] = W.Codec.to_numpy(c.values).view(dt)[:n].copy()
+        else:
+            d["counts"] = W.Codec.to_numpy(c.counts).view(np.uint64)
+            d["offs"] = W.Codec.to_numpy(c.offs).view(np.uint64)
+            tot = int(d["offs"][n])
+            d["values"] = (W.Codec.to_numpy(c.values).view(dt)[:tot].copy() if tot
+                           else np.zeros(0, dt))
+        out.append(d)
+    return out
+
+
+def gpu_encode(codec, fmt_s, ocols, n, align=1, packed=None):
+    fmt = W.Format(fmt_s)
+    wire = codec.encode(fmt, dev_cols(codec, fmt, ocols), n, align=align, packed=packed)
+    torch.cuda.synchronize()
+    return fmt, wire
+
+
+def wire_from_numpy(codec, n, arena, offs=None, lens=None, stride=0):
+    a = codec.to_device(arena) if arena.size else codec.empty(1, torch.uint8)
+    return W.WireWave(a, n, None if offs is None else codec.to_device(offs),
+                      None if lens is None else codec.to_device(lens), stride)
+
+
+VAR_FORMATS = ["%d %uld %lf %s %auc", "%af", "%s", "%ad %ad %alf", "%auc", "%ahd %s %ald %c",
+               "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s",
+               "%Ac %Auc %Ahd %Auhd %Ad %Aud %Ald %Auld %Af %Alf", "%lf %alf %f %af %hd %ahd"]
+FIXED_FORMATS = ["%d", "%lf %d", "%c %uc %hd %uhd %d %ud %ld %uld %f %lf", "%c", "%hd %c", "%uld",
+                 "%f %f %f"]
+
+
+@pytest.mark.parametrize("fmt_s", VAR_FORMATS)
+@pytest.mark.parametrize("n,align", [(0, 1), (1, 1), (5, 16), (257, 1), (1000, 8)])
+def test_var_encode_decode_parity(codec, fmt_s, n, align):
+    ocols = make_wave(fmt_s, n, seed=n + 13 * align, max_count=37)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align)
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, n, align=align)
+    assert np.array_equal(W.Codec.to_numpy(wire.lens).view(np.uint64), lens)
+    assert np.array_equal(W.Codec.to_numpy(wire.offsets).view(np.uint64), offs)
+    got = W.Codec.to_numpy(wire.arena)[:arena.size]
+    assert np.array_equal(got, arena), "encoded bytes differ"
+    for bo, src in ((W.LITTLEENDIAN, arena), (W.BIGENDIAN, to_sender_order(fmt_s, arena, offs, lens))):
+        ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, lens, bo)
+        dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, lens), bo)
+        torch.cuda.synchronize()
+        assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+        assert columns_equal(host_cols(fmt, dcols, n), ref_cols), (fmt_s, n, bo)
+        assert columns_equal(ref_cols, ocols)
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("fmt_s", FIXED_FORMATS)
+@pytest.mark.parametrize("n,align", [(0, 1), (1, 1), (3, 4), (256, 1), (257, 16), (5000, 1)])
+def test_fixed_encode_decode_parity(codec, fmt_s, n, align):
+    ocols = make_wave(fmt_s, n, seed=3 * n + align)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align)
+    # packed layout (LDS-staged rows path)
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, n, align=align)
+    assert wire.offsets is None and wire.stride == (int(offs[1]) if n else wire.stride)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    # explicit offsets (generic walker path)
+    fmt, wire2 = gpu_encode(codec, fmt_s, ocols, n, align=align, packed=False)
+    assert np.array_equal(W.Codec.to_numpy(wire2.arena)[:arena.size], arena)
+    assert np.array_equal(W.Codec.to_numpy(wire2.offsets).view(np.uint64), offs)
+    for bo, src in ((W.LITTLEENDIAN, arena), (W.BIGENDIAN, to_sender_order(fmt_s, arena, offs, lens))):
+        ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, lens, bo)
+        for w in (wire_from_numpy(codec, n, src, stride=wire.stride),
+                  wire_from_numpy(codec, n, src, offs, lens)):
+            dcols, ok = codec.decode(fmt, w, bo)
+            torch.cuda.synchronize()
+            assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+            assert columns_equal(host_cols(fmt, dcols, n), ref_cols), (fmt_s, n, bo)
+
+
+def test_golden_packet_through_the_gpu(codec, golden):
+    g = golden["packet"]
+    v = g["values"]
+    fmt_s = g["fmt"]
+
+    def arr(t, dt, vals):
+        vals = np.asarray(vals, dt)
+        return {"type": t, "counts": np.array([vals.size], np.uint64),
+                "offs": np.array([0, vals.size], np.uint64), "values": vals}
+    ocols = [{"type": O.INT32_T, "values": np.array([v["d"]], np.int32)},
+             {"type": O.UINT64_T, "values": np.array([v["uld"]], np.uint64)},
+             {"type": O.DOUBLE_T, "values": np.array([v["lf"]], np.float64)},
+             arr(O.STRING_T, np.uint8, np.frombuffer(v["s"].encode() + b"\0", np.uint8)),
+             arr(O.UCHAR_ARRAY_T, np.uint8, v["auc"]), arr(O.FLOAT_ARRAY_T, np.float32, v["af"])]
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, 1)
+    assert W.Codec.to_numpy(wire.arena)[:57].tobytes() == bytes.fromhex(g["buf_hex"])
+    hdrs, stride = codec.encode_headers(fmt, 1, stream_id=g["stream_id"], tag=g["tag"],
+                                        src_rank=g["src_rank"])
+    assert stride == 49 and W.Codec.to_numpy(hdrs)[:49].tobytes() == bytes.fromhex(g["hdr_hex"])
+    # the captured bytes decode to the captured values
+    raw = np.frombuffer(bytes.fromhex(g["buf_hex"]), np.uint8)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, 1, raw, np.array([0, 57], np.uint64),
+                                                  np.array([57], np.uint64)))
+    assert int(ok[0]) == 1 and columns_equal(host_cols(fmt, dcols, 1), ocols)
+    # swap known answer: 00 00 01 02 from a big-endian sender is 258
+    s = golden["swap"]
+    f1 = W.Format(s["fmt"])
+    dcols, ok = codec.decode(f1, wire_from_numpy(codec, 1, np.frombuffer(bytes.fromhex(s["bytes_hex"]), np.uint8),
+                                                 stride=4), s["sender_byteorder"])
+    assert int(ok[0]) == 1 and int(dcols[0].values[0]) == s["value"]
+
+
+def test_reference_test_values_round_trip(codec, golden):
+    """The packets of tests/test_basic_FE.C and tests/test_arrays_FE.C, n back-ends at once."""
+    g = golden["basic_test"]
+    fmt_s = g["fmt"]
+    n = 16
+    toks = [t[1:] for t in fmt_s.split()]
+    ocols = []
+    for tok, val in zip(toks, g["values"]):
+        t = O.fmt_types("%" + tok)[0]
+        if tok == "s":
+            b = np.frombuffer(val.encode() + b"\0", np.uint8)
+            cnt = np.full(n, b.size, np.uint64)
+            offs = np.arange(n + 1, dtype=np.uint64) * np.uint64(b.size)
+            ocols.append({"type": t, "counts": cnt, "offs": offs, "values": np.tile(b, n)})
+        else:
+            if isinstance(val, str):
+                val = ord(val)
+            ocols.append({"type": t, "values": np.full(n, val, O.elem_dtype(t))})
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, n)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    dcols, ok = codec.decode(fmt, wire)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+    a = golden["arrays_test"]
+    for tok, val in a["values"].items():
+        fmt_s = "%" + tok
+        t = O.fmt_types(fmt_s)[0]
+        dt = O.elem_dtype(t)
+        m = a["array_len"]
+        ocols = [{"type": t, "counts": np.full(4, m, np.uint64),
+                  "offs": np.arange(5, dtype=np.uint64) * np.uint64(m), "values": np.full(4 * m, val, dt)}]
+        arena, offs, lens = O.wave_encode(fmt_s, ocols, 4)
+        fmt, wire = gpu_encode(codec, fmt_s, ocols, 4)
+        assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+        be = to_sender_order(fmt_s, arena, offs, lens)
+        dcols, ok = codec.decode(fmt, wire_from_numpy(codec, 4, be, offs, lens), W.BIGENDIAN)
+        assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, 4), ocols), tok
+
+
+@pytest.mark.parametrize("fmt_s,n,maxc", [("%af", 37, 20000), ("%auc", 3000, 600), ("%ald", 9, 9000),
+                                          ("%ahd %s %alf", 300, 700), ("%auc", 70000, 3)])
+def test_segments_crossing_chunks(codec, fmt_s, n, maxc):
+    """Arrays longer and shorter than the 16 KiB streaming chunk, odd alignments."""
+    ocols = make_wave(fmt_s, n, seed=n, max_count=maxc)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, n)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    be = to_sender_order(fmt_s, arena, offs, lens)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, be, offs, lens), W.BIGENDIAN)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+def test_zero_length_and_empty(codec):
+    fmt_s = "%ad %s %auc"
+    n = 6
+    ocols = make_wave(fmt_s, n, 5, counts={0: np.zeros(n, np.uint64), 1: np.zeros(n, np.uint64),
+                                           2: np.array([0, 3, 0, 0, 1, 0], np.uint64)})
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    fmt, wire = gpu_encode(codec, fmt_s, ocols, n)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    dcols, ok = codec.decode(fmt, wire)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+    # all arrays empty
+    ocols = make_wave("%af", 50, 1, max_count=0)
+    arena, offs, lens = O.wave_encode("%af", ocols, 50)
+    fmt, wire = gpu_encode(codec, "%af", ocols, 50)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    dcols, ok = codec.decode(fmt, wire)
+    assert bool(ok.all()) and int(dcols[0].offs[50]) == 0
+
+
+def test_truncated_packets_fail_per_packet(codec):
+    fmt_s = "%d %ad %lf"
+    n = 600
+    ocols = make_wave(fmt_s, n, 11, max_count=12)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    short = lens.copy()
+    cut = (np.arange(n) % 3 == 0)
+    short[cut] = (short[cut] * np.uint64(2)) // np.uint64(3)
+    short[5] = 0
+    bad = arena.copy()
+    bad[int(offs[7]) + 4:int(offs[7]) + 12] = np.frombuffer(np.uint64(1 << 40).tobytes(), np.uint8)
+    for bo, src in ((W.LITTLEENDIAN, bad), (W.BIGENDIAN, to_sender_order(fmt_s, arena, offs, lens))):
+        ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, short, bo)
+        assert 0 < ref_ok.sum() < n
+        fmt = W.Format(fmt_s)
+        dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, short), bo)
+        assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+        assert columns_equal(host_cols(fmt, dcols, n), ref_cols)
+    # fixed format, packed rows path, with explicit short lengths
+    fmt_s = "%d %lf %hd"
+    ocols = make_wave(fmt_s, n, 12)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    short = lens.copy()
+    short[::4] = 9
+    short[1::4] = 3
+    ref_cols, ref_ok = O.wave_decode(fmt_s, arena, offs, short, O.LITTLE)
+    fmt = W.Format(fmt_s)
+    w = wire_from_numpy(codec, n, arena, None, short, stride=14)
+    dcols, ok = codec.decode(fmt, w)
+    assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+    assert columns_equal(host_cols(fmt, dcols, n), ref_cols)
+
+
+def test_headers_parity(codec):
+    fmt_s = "%d %uld %lf %s %auc"
+    fmt = W.Format(fmt_s)
+    n = 700
+    src = np.arange(n, dtype=np.uint32)
+    tags = (100 + (np.arange(n) % 7)).astype(np.int32)
+    hdrs, stride = codec.encode_headers(fmt, n, stream_id=W.USER_STRM_BASE_ID, tags=codec.to_device(tags),
+                                        src_ranks=codec.to_device(src))
+    h = W.Codec.to_numpy(hdrs).reshape(n, stride)
+    for i in (0, 1, 255, 256, n - 1):
+        assert h[i].tobytes() == O.header_encode(W.USER_STRM_BASE_ID, int(tags[i]), int(src[i]), fmt_s).tobytes()
+    out = codec.decode_headers(fmt, n, hdrs, stride=stride)
+    assert bool(out["ok"].all())
+    assert np.array_equal(W.Codec.to_numpy(out["src_rank"]).view(np.uint32), src)
+    assert np.array_equal(W.Codec.to_numpy(out["tag"]), tags)
+    assert bool((out["stream_id"] == W.USER_STRM_BASE_ID).all()) and bool((out["byteorder"] == 0).all())
+    # headers from a big-endian sender, with a destination list, and one foreign format
+    raw = []
+    for i in range(5):
+        hb = O.header_encode(77 + i, -3 - i, 1000 + i, fmt_s if i != 3 else "%d", dest=[1, 2, 3][: i % 4])
+        hb = hb.copy()
+        flen = len((fmt_s if i != 3 else "%d")) + 1
+        for a, w in ((0, 4), (4, 4), (8, 4), (12, 4), (16 + flen, 8)):
+            hb[a:a + w] = hb[a:a + w][::-1]
+        nd = i % 4
+        for k in range(nd):
+            a = 16 + flen + 8 + 4 * k
+            hb[a:a + 4] = hb[a:a + 4][::-1]
+        hb[-1] = 1
+        raw.append(hb)
+    lens = np.array([len(x) for x in raw], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    out = codec.decode_headers(fmt, 5, codec.to_device(np.concatenate(raw)),
+                               offsets=codec.to_device(offs), lens=codec.to_device(lens))
+    assert W.Codec.to_numpy(out["ok"]).tolist() == [1, 1, 1, 0, 1]
+    assert W.Codec.to_numpy(out["stream_id"]).tolist() == [77, 78, 79, 80, 81]
+    assert W.Codec.to_numpy(out["tag"]).tolist() == [-3, -4, -5, -6, -7]
+    assert W.Codec.to_numpy(out["ndest"]).tolist()[:3] == [0, 1, 2]
+    assert W.Codec.to_numpy(out["byteorder"]).tolist() == [1, 1, 1, 0, 1]
+
+
+def test_full_size_array_wave_properties(codec):
+    """BASELINE config 3 shape: '%af' with 65,536 floats per packet from a big-endian sender.
+    Size-independent properties: decode(BE) == element-wise byte reversal; encode(decode(x))
+    is the little-endian wire; decode(encode(decode(x))) == decode(x)."""
+    n, m = 1024, 65536
+    fmt = W.Format("%af")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    vals = torch.randint(-2**31, 2**31 - 1, (n, m), dtype=torch.int32, device="cuda", generator=g)
+    # wire as the big-endian sender wrote it: u64 count then m floats, every item reversed
+    stride = 8 + 4 * m
+    be = torch.empty((n, stride), dtype=torch.uint8, device="cuda")
+    be[:, :8] = torch.tensor(list(int(m).to_bytes(8, "big")), dtype=torch.uint8, device="cuda")
+    be[:, 8:] = vals.view(torch.uint8).view(n, m, 4).flip(-1).reshape(n, 4 * m)
+    offs = torch.arange(n + 1, dtype=torch.int64, device="cuda") * stride
+    lens = torch.full((n,), stride, dtype=torch.int64, device="cuda")
+    wire = W.WireWave(be.view(-1), n, offs, lens, 0)
+    cols, ok = codec.decode(fmt, wire, W.BIGENDIAN)
+    assert bool(ok.all()) and int(cols[0].offs[n]) == n * m
+    assert bool((cols[0].counts == m).all())
+    assert torch.equal(cols[0].values.view(n, m), vals)
+    le = codec.encode(fmt, cols, n)
+    assert torch.equal(le.offsets, offs) and torch.equal(le.lens, lens)
+    lw = le.arena.view(n, stride)
+    assert torch.equal(lw[:, 8:].contiguous().view(torch.int32).view(n, m), vals)
+    assert torch.equal(lw[:, :8].contiguous().view(torch.int64).view(-1), torch.full((n,), m, dtype=torch.int64, device="cuda"))
+    cols2, ok2 = codec.decode(fmt, le, W.LITTLEENDIAN)
+    assert bool(ok2.all()) and torch.equal(cols2[0].values, cols[0].values)
+    assert codec.status() == 0

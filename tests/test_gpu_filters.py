@@ -1,0 +1,171 @@
+"""tfilter_Sum / Min / Max / Avg on the GPU against the oracle, through the C ABI.
+
+Bar: bit-exact for every type when the GPU and the oracle apply the same shape
+(flat = one reference filter call over the wave; tree = the declared level-by-level
+shape).  Against the FLAT reference result the tree shape is additionally held to
+1e-6 relative for double; for float the tree differs from a 64K-term sequential sum by
+rounding (about 1e-5 relative), which is why the shape is declared and bit-checked."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O, random_values, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+
+TYPES = [("c", O.CHAR_T, np.int8), ("uc", O.UCHAR_T, np.uint8), ("hd", O.INT16_T, np.int16),
+         ("uhd", O.UINT16_T, np.uint16), ("d", O.INT32_T, np.int32), ("ud", O.UINT32_T, np.uint32),
+         ("ld", O.INT64_T, np.int64), ("uld", O.UINT64_T, np.uint64), ("f", O.FLOAT_T, np.float32),
+         ("lf", O.DOUBLE_T, np.float64)]
+OPS = [("sum", O.SUM), ("min", O.MIN), ("max", O.MAX), ("avg", O.AVG)]
+SIZES = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4097, 65536]
+
+
+def values_for(dt, n, seed, op):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        # magnitudes that make a float sum order-sensitive but finite
+        u = splitmix64(seed, n)
+        mant = (u % np.uint64(2_000_001)).astype(np.float64) / 1e3 - 1000.0
+        scale = np.array([1e-3, 1.0, 1e3, 1e6])[(u >> np.uint64(40)) % np.uint64(4)]
+        return (mant * scale).astype(dt)
+    v = random_values(dt, n, seed)
+    if op == O.AVG and dt.kind == "i":
+        v = np.where(v == np.iinfo(dt).min, dt.type(1), v)      # keeps INT_MIN / -1 out
+    return v
+
+
+def counts_for(n, seed):
+    return (splitmix64(seed + 99, n) % np.uint64(5) + np.uint64(1)).astype(np.int32)
+
+
+def run_gpu(codec, op, t, dt, vals, cnt, shape):
+    dv = codec.to_device(vals)
+    dc = codec.to_device(cnt) if cnt is not None else None
+    res, ok = codec.filter_columns(op, t, dv, dc, shape)
+    torch.cuda.synchronize()
+    return W.result_value(res, ok, np.dtype(dt), op)
+
+
+@pytest.mark.parametrize("tok,t,dt", TYPES)
+@pytest.mark.parametrize("opname,op", OPS)
+def test_filter_parity_flat_and_tree(codec, tok, t, dt, opname, op):
+    for n in SIZES:
+        vals = values_for(dt, n, 17 * n + t, op)
+        cnt = counts_for(n, n) if op == O.AVG else None
+        # flat: exactly one reference filter call over the wave
+        if n <= 4097:
+            ref = O.filter_flat(op, t, vals, cnt)
+            got = run_gpu(codec, op, t, dt, vals, cnt, W.SHAPE_FLAT)
+            assert got is not None and ref is not None
+            assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (tok, opname, n, "flat")
+            if op == O.AVG:
+                assert got[1] == ref[1]
+        # tree: the declared shape, bit for bit
+        ref = O.filter_tree(op, t, vals, cnt, W.TREE_FANINS)
+        got = run_gpu(codec, op, t, dt, vals, cnt, W.SHAPE_TREE)
+        assert got is not None and ref is not None
+        assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (tok, opname, n, "tree")
+        if op == O.AVG:
+            assert got[1] == ref[1]
+        # integer SUM and NaN-free MIN/MAX do not depend on the shape at all
+        if op in (O.MIN, O.MAX) or (op == O.SUM and np.dtype(dt).kind != "f"):
+            flat = O.filter_flat(op, t, vals, cnt)
+            assert np.asarray(got[0]).tobytes() == np.asarray(flat[0]).tobytes()
+        # double: the tree is within 1e-6 relative of the flat reference fold
+        if np.dtype(dt) == np.float64 and op in (O.SUM, O.AVG):
+            flat = O.filter_flat(op, t, vals, cnt)
+            scale = float(np.sum(np.abs(vals.astype(np.float64)) * (cnt if cnt is not None else 1)))
+            scale = scale / (float(np.sum(cnt)) if cnt is not None else 1.0)
+            assert abs(float(got[0]) - float(flat[0])) <= 1e-6 * max(scale, 1e-300)
+
+
+def test_native_filters_expectations(codec, golden):
+    """tests/test_NativeFilters_FE.C: TFILTER_SUM over num_backends copies of VAL."""
+    g = golden["native_filters_test"]
+    for tok, t, dt in TYPES:
+        for nb in g["num_backends"]:
+            vals = np.full(nb, g["values"][tok], dtype=dt)
+            comp = np.zeros(1, dtype=dt)
+            with np.errstate(over="ignore"):
+                for _ in range(nb):
+                    comp[0] = comp[0] + np.dtype(dt).type(g["values"][tok])
+            got = run_gpu(codec, O.SUM, t, dt, vals, None, W.SHAPE_FLAT)
+            assert np.asarray(got[0]).tobytes() == comp[0].tobytes(), (tok, nb)
+
+
+def test_filter_known_answers(codec, golden):
+    v = np.array(golden["filters"][0]["values"], np.float32)
+    for case, op in zip(golden["filters"][:3], (O.SUM, O.MIN, O.MAX)):
+        got = run_gpu(codec, op, O.FLOAT_T, np.float32, v, None, W.SHAPE_FLAT)
+        assert "%f" % got[0] == case["printf_f"]
+    a = golden["filters"][3]
+    got = run_gpu(codec, O.AVG, O.INT32_T, np.int32, np.array(a["values"], np.int32),
+                  np.array(a["counts"], np.int32), W.SHAPE_FLAT)
+    assert (int(got[0]), got[1]) == (a["value"], a["count"])
+
+
+def test_nan_and_signed_zero_rules(codec):
+    nan = np.float32("nan")
+    cases = [np.array([1, nan, 2], np.float32), np.array([1, 2, nan], np.float32),
+             np.array([nan, 5, 7], np.float32), np.array([0.0, -0.0], np.float32),
+             np.array([-0.0, 0.0], np.float32), np.array([-0.0, -0.0], np.float32)]
+    for v in cases:
+        for op in (O.MIN, O.MAX, O.SUM):
+            if op == O.SUM and np.isnan(v).any():
+                continue
+            ref = O.filter_flat(op, O.FLOAT_T, v)
+            got = run_gpu(codec, op, O.FLOAT_T, np.float32, v, None, W.SHAPE_FLAT)
+            assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (v, op)
+            ref = O.filter_tree(op, O.FLOAT_T, v, None, W.TREE_FANINS)
+            got = run_gpu(codec, op, O.FLOAT_T, np.float32, v, None, W.SHAPE_TREE)
+            assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (v, op)
+
+
+def test_empty_wave_and_zero_counts(codec):
+    res, ok = codec.filter_raw(O.SUM, O.INT32_T, None, 4, None, 4, 0)
+    assert int(ok.item()) == 0
+    got = run_gpu(codec, O.AVG, O.INT32_T, np.int32, np.array([5, 6], np.int32), np.array([0, 0], np.int32),
+                  W.SHAPE_TREE)
+    assert got is None
+
+
+@pytest.mark.parametrize("shape", [W.SHAPE_FLAT, W.SHAPE_TREE])
+def test_fused_decode_filter_on_the_wire(codec, shape):
+    """BASELINE config 2: 65,536 '%d' packets decoded and summed; config 5 shape '%lf %d'."""
+    n = 65536
+    vals = random_values(np.int32, n, 2)
+    cols = [{"type": O.INT32_T, "values": vals}]
+    arena, offs, lens = O.wave_encode("%d", cols, n)
+    fmt = W.Format("%d")
+    for bo in (W.LITTLEENDIAN, W.BIGENDIAN):
+        src = arena if bo == 0 else arena.reshape(n, 4)[:, ::-1].copy().reshape(-1)
+        wire = W.WireWave(codec.to_device(src), n, None, None, 4)
+        for op in (O.SUM, O.MIN, O.MAX):
+            res, ok = codec.filter_wire(op, fmt, wire, bo, shape)
+            got = W.result_value(res, ok, np.dtype(np.int32), op)
+            ref = O.filter_flat(op, O.INT32_T, vals)
+            assert int(got[0]) == int(ref[0])
+    n = 20000
+    v = values_for(np.float64, n, 5, O.AVG)
+    c = counts_for(n, 5)
+    cols = [{"type": O.DOUBLE_T, "values": v}, {"type": O.INT32_T, "values": c}]
+    arena, offs, lens = O.wave_encode("%lf %d", cols, n)
+    fmt = W.Format("%lf %d")
+    be = arena.reshape(n, 12).copy()
+    be[:, :8] = arena.reshape(n, 12)[:, 7::-1]
+    be[:, 8:] = arena.reshape(n, 12)[:, :7:-1]
+    for bo, src in ((0, arena), (1, be.reshape(-1))):
+        wire = W.WireWave(codec.to_device(src), n, None, None, 12)
+        res, ok = codec.filter_wire(O.AVG, fmt, wire, bo, shape)
+        got = W.result_value(res, ok, np.dtype(np.float64), O.AVG)
+        ref = (O.filter_flat(O.AVG, O.DOUBLE_T, v, c) if shape == W.SHAPE_FLAT
+               else O.filter_tree(O.AVG, O.DOUBLE_T, v, c, W.TREE_FANINS))
+        assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes() and got[1] == ref[1]
+        # the 16 result bytes are the data of the output packet '%lf %d'
+        out_cols = [{"type": O.DOUBLE_T, "values": np.array([ref[0]])},
+                    {"type": O.INT32_T, "values": np.array([ref[1]], np.int32)}]
+        out_arena, _, _ = O.wave_encode("%lf %d", out_cols, 1)
+        assert res.cpu().numpy()[:12].tobytes() == out_arena.tobytes()
