@@ -1,0 +1,330 @@
+#!/usr/bin/env python3
+"""Headline benchmark: device-resident PDR decode+encode GB/s per wave.
+
+Workload (BASELINE.json config 3, the one the GB/s metric is quoted on): per GPU a wave of
+4,096 packets, each '%af' with 65,536 floats, written by a BIG-endian sender.  One step =
+  decode : walk + count scan + byte-reversing payload kernel  (wire -> float column)
+  sizeof : per-packet lengths + offset scan                   (the pdr_sizeof pass)
+  encode : prefixes + payload kernel                          (float column -> little-endian wire)
+with every buffer resident in HBM before the clock starts and no host synchronisation
+inside a step.  N GPUs each take their own packet range of an N x 4,096-packet wave
+(weak scaling, no data-path collective).
+
+Bytes counted are ALGORITHMIC (minimum traffic): decode = data bytes read + decoded bytes
+written; encode = decoded bytes read + data bytes written + 8(n+1) offset bytes.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from mrnet_amd import wave as W  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=50)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--packets", type=int, default=4096, help="packets per GPU")
+    p.add_argument("--elems", type=int, default=65536, help="floats per packet")
+    p.add_argument("--cpu-packets", type=int, default=1024, help="packets of the CPU baseline sample")
+    p.add_argument("--cpu-reps", type=int, default=3)
+    p.add_argument("--no-cpu", action="store_true")
+    p.add_argument("--no-extras", action="store_true")
+    return p.parse_args()
+
+
+def make_be_wave(n, m, seed, device):
+    """n packets '%af'[m] as a big-endian sender wrote them, built on the device."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    stride = 8 + 4 * m
+    wire = torch.empty((n, stride), dtype=torch.uint8, device=device)
+    wire[:, :8] = torch.tensor(list(int(m).to_bytes(8, "big")), dtype=torch.uint8, device=device)
+    step = max(1, min(n, (1 << 28) // (4 * m)))
+    for a in range(0, n, step):          # in slices: the generator's scratch stays small
+        b = min(n, a + step)
+        v = torch.randint(-2**31, 2**31 - 1, (b - a, m), dtype=torch.int32, device=device, generator=g)
+        wire[a:b, 8:] = v.view(torch.uint8).view(b - a, m, 4).flip(-1).reshape(b - a, 4 * m)
+        del v
+    offs = torch.arange(n + 1, dtype=torch.int64, device=device) * stride
+    lens = torch.full((n,), stride, dtype=torch.int64, device=device)
+    return W.WireWave(wire.view(-1), n, offs, lens, 0)
+
+
+class ArrayWaveStep:
+    """Preallocated decode -> sizeof -> encode of one '%af' wave."""
+
+    def __init__(self, codec, n, m, seed):
+        self.codec, self.n, self.m = codec, n, m
+        dev = codec.device
+        self.fmt = W.Format("%af")
+        self.src = make_be_wave(n, m, seed, dev)
+        self.cols = [W.Column(torch.empty(n * m, dtype=torch.int32, device=dev),
+                              torch.empty(n, dtype=torch.int64, device=dev),
+                              torch.empty(n + 1, dtype=torch.int64, device=dev), capacity=n * m)]
+        self.ok = torch.empty(n, dtype=torch.int32, device=dev)
+        self.out_lens = torch.empty(n, dtype=torch.int64, device=dev)
+        self.out_offs = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        self.dst = W.WireWave(torch.empty(n * (8 + 4 * m), dtype=torch.uint8, device=dev), n,
+                              self.out_offs, self.out_lens, 0)
+        data = n * (8 + 4 * m)
+        payload = n * 4 * m
+        self.bytes_decode = data + payload
+        self.bytes_encode = payload + data + 8 * (n + 1)
+        self.bytes_step = self.bytes_decode + self.bytes_encode
+        self.bytes_copy_kernel = 2 * payload          # one launch of the payload kernel
+
+    def decode(self):
+        self.codec.decode_begin(self.fmt, self.src, self.cols, self.ok, W.BIGENDIAN, want_totals=False)
+
+    def decode_payload(self):
+        self.codec.decode_finish(self.fmt, self.src, self.cols, W.BIGENDIAN)
+
+    def encode(self):
+        L = self.codec._lib
+        import ctypes as C
+        ok = L.mrpdr_wave_sizeof(self.codec.handle, self.fmt.handle, W._c_columns(self.cols), self.n, 1,
+                                 self.out_lens.data_ptr(), self.out_offs.data_ptr(), None,
+                                 torch.cuda.current_stream().cuda_stream)
+        assert ok, W.capi.last_error()
+        self.codec.encode_into(self.fmt, self.cols, self.dst)
+
+    def step(self):
+        self.decode()
+        self.decode_payload()
+        self.encode()
+
+    def verify(self):
+        """decode(BE) is the byte reversal of the wire; encode gives the LE wire of the same values."""
+        n, m = self.n, self.m
+        stride = 8 + 4 * m
+        src = self.src.arena.view(n, stride)
+        k = min(n, 64)
+        want = src[:k, 8:].reshape(k, m, 4).flip(-1).reshape(k, 4 * m).contiguous().view(torch.int32)
+        got = self.cols[0].values.view(n, m)[:k]
+        assert torch.equal(got, want), "decoded values differ from the byte-reversed wire"
+        dst = self.dst.arena.view(n, stride)
+        assert torch.equal(dst[:k, 8:].contiguous().view(torch.int32), want), "encoded payload differs"
+        assert bool((dst[:, :8].contiguous().view(torch.int64) == m).all()), "encoded counts differ"
+        assert bool(self.ok.all()) and self.codec.status() == 0
+
+
+def cpu_baseline(n, m, reps):
+    """The oracle (CPU restatement of the reference's per-element path) on a bounded sample
+    of the same workload, one thread."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    vals = rng.integers(0, 2**32, size=n * m, dtype=np.uint32)
+    counts = np.full(n, m, np.uint64)
+    offs_e = np.arange(n + 1, dtype=np.uint64) * np.uint64(m)
+    cols = [{"type": O.FLOAT_ARRAY_T, "counts": counts, "offs": offs_e, "values": vals.view(np.float32)}]
+    arena, offs, lens = O.wave_encode("%af", cols, n)
+    # the big-endian sender's bytes of the same packets
+    be = arena.reshape(n, 8 + 4 * m).copy()
+    be[:, :8] = be[:, 7::-1]
+    be[:, 8:] = be[:, 8:].reshape(n, m, 4)[:, :, ::-1].reshape(n, 4 * m)
+    be = be.reshape(-1)
+    data, payload = n * (8 + 4 * m), n * 4 * m
+    nbytes = (data + payload) + (payload + data + 8 * (n + 1))
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        dec, ok = O.wave_decode("%af", be, offs, lens, O.BIG)
+        t1 = time.perf_counter()
+        out, _, _ = O.wave_encode("%af", dec, n)
+        t2 = time.perf_counter()
+        dt = t2 - t0
+        if best is None or dt < best[0]:
+            best = (dt, t1 - t0, t2 - t1)
+    assert ok.all() and np.array_equal(out, arena)
+    return {"value": round(nbytes / best[0] / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "%d packets x '%%af'[%d] (%.0f MiB of data), decode big-endian + sizeof + encode, "
+                      "best of %d, decode %.2f s encode %.2f s" % (n, m, data / 2**20, reps, best[1], best[2])}
+
+
+def small_wave_extras(codec):
+    """Launch-bound configs, reported as time per wave (not the headline)."""
+    out = {}
+    dev = codec.device
+    # config 2: 65,536 x '%d' -- fused decode + Sum straight on the wire, then full decode + encode
+    n = 65536
+    fmt = W.Format("%d")
+    vals = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device=dev)
+    wire = W.WireWave(vals.view(torch.uint8).clone(), n, None, None, 4)
+    res = torch.empty(16, dtype=torch.uint8, device=dev)
+    rok = torch.empty(1, dtype=torch.int32, device=dev)
+    cols = codec.alloc_columns(fmt, n)
+    ok = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def c2():
+        codec.filter_raw(W.TFILTER_SUM, W.DataType.INT32_T, wire.arena.data_ptr(), 4, None, 4, n, 0,
+                         W.SHAPE_TREE, res, rok)
+        codec.decode_into(fmt, wire, cols, ok)
+        codec.encode_into(fmt, cols, wire)
+    out["c2_us_per_wave"] = round(time_call(c2, 200) * 1e6, 2)
+    assert int(res[:4].view(torch.int32).item()) == int(vals.sum(dtype=torch.int32).item())
+    # config 5 shape: '%lf %d', fused Min / Max / Avg on the wire (one GPU's 131,072-packet shard)
+    n5 = 131072
+    fmt5 = W.Format("%lf %d")
+    v = (torch.randn(n5, dtype=torch.float64, device=dev) * 1e-4 + 1e-3)
+    rows = torch.empty((n5, 12), dtype=torch.uint8, device=dev)
+    rows[:, :8] = v.view(torch.uint8).view(n5, 8)
+    rows[:, 8:] = torch.ones(n5, dtype=torch.int32, device=dev).view(torch.uint8).view(n5, 4)
+    w5 = W.WireWave(rows.view(-1), n5, None, None, 12)
+    r3 = [torch.empty(16, dtype=torch.uint8, device=dev) for _ in range(3)]
+
+    def c5():
+        for r, op in zip(r3, (W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
+            codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
+                             n5, 0, W.SHAPE_TREE, r, rok)
+    out["c5_shard_us_per_wave"] = round(time_call(c5, 200) * 1e6, 2)
+    assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
+    assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
+    return out
+
+
+def time_call(fn, reps):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def end_to_end(step_obj, reps=5):
+    """Same step, but starting and ending in (pinned) host memory: H2D + kernels + D2H."""
+    s = step_obj
+    host_in = torch.empty(s.src.arena.numel(), dtype=torch.uint8).pin_memory()
+    host_in.copy_(s.src.arena)
+    host_out = torch.empty(s.dst.arena.numel(), dtype=torch.uint8).pin_memory()
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        s.src.arena.copy_(host_in, non_blocking=True)
+        s.step()
+        host_out.copy_(s.dst.arena, non_blocking=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return s.bytes_step / best / 1e9, best
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if a.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+
+    codec = W.Codec(device=local, max_packets=max(a.packets, 1 << 18))
+    st = ArrayWaveStep(codec, a.packets, a.elems, seed=3 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        st.step()
+    barrier()
+    st.verify()
+    barrier()
+
+    # timed region: exactly K steps; the payload kernels are bracketed by events on the
+    # stream they are launched on (torch's current stream)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        st.decode()
+        ev[k][0].record()
+        st.decode_payload()
+        ev[k][1].record()
+        st.encode()
+        ev[k][2].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    dec_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / a.steps
+    enc_ms = sum(e[1].elapsed_time(e[2]) for e in ev) / a.steps
+
+    total_bytes = st.bytes_step * world * a.steps
+    value = total_bytes / dt / 1e9
+
+    out = None
+    if rank == 0:
+        achieved = st.bytes_copy_kernel / (dec_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_copy_decode_swap4_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "device-resident PDR decode+encode GB/s per wave",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C3: %d packets x '%%af'[%d] per GPU from a big-endian sender; "
+                                   "decode -> sizeof -> encode little-endian, device-resident"
+                                   % (a.packets, a.elems),
+                       "packets_per_gpu": a.packets, "elems_per_packet": a.elems,
+                       "algorithmic_bytes_per_step_per_gpu": st.bytes_step,
+                       "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2)},
+            "roofline": {"bound": "hbm", "kernel": "k_copy<4,swap,decode>",
+                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "bytes_per_launch": st.bytes_copy_kernel,
+                         "avg_launch_ms": round(dec_ms, 4),
+                         "encode_side": {"avg_ms_sizeof_prefix_payload": round(enc_ms, 4),
+                                         "achieved": round(st.bytes_encode / (enc_ms * 1e-3) / 1e9, 1)}},
+        }
+    # extras and the CPU leg run after the timed region, rank 0 at N=1 only
+    if rank == 0 and world == 1:
+        if not a.no_extras:
+            extra = small_wave_extras(codec)
+            gbps, sec = end_to_end(st)
+            extra["e2e_gbps_pinned_h2d_kernels_d2h"] = round(gbps, 2)
+            extra["e2e_ms_per_wave"] = round(sec * 1e3, 3)
+            out["extra"] = extra
+        if not a.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
+    if rank == 0:
+        out.setdefault("cpu_baseline", None)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

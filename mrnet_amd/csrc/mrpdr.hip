@@ -272,8 +272,8 @@ static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *
     if (n && !w->base) return fail("%s: NULL arena", who);
     out->base = w->base; out->offsets = w->offsets; out->lens = w->lens;
     out->stride = w->stride; out->bytes = w->bytes;
-    if (!w->lens && !f->fixed) return fail("%s: lens is required for variable-length formats", who);
-    if (!w->offsets) {
+    if (n && !w->lens && !f->fixed) return fail("%s: lens is required for variable-length formats", who);
+    if (n && !w->offsets) {
         if (!f->fixed) return fail("%s: offsets are required for variable-length formats", who);
         if (w->stride < f->dev.fixed_bytes)
             return fail("%s: stride %llu is shorter than the packet (%u bytes)", who,
