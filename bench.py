@@ -40,8 +40,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--packets", type=int, default=4096, help="packets per GPU")
     p.add_argument("--elems", type=int, default=65536, help="floats per packet")
-    p.add_argument("--cpu-packets", type=int, default=1024, help="packets of the CPU baseline sample")
-    p.add_argument("--cpu-reps", type=int, default=3)
+    p.add_argument("--cpu-packets", type=int, default=4096, help="packets of the CPU baseline sample")
+    p.add_argument("--cpu-reps", type=int, default=4)
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-extras", action="store_true")
     return p.parse_args()

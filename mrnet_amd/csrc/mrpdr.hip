@@ -172,8 +172,11 @@ struct mrpdr_ctx {
     Partial  *partials;       // filter partials
     uint64_t  npartials;
     uint64_t *totals;         // per-field totals gathered for the host
+    ChunkDesc *desc;          // chunk descriptors of the payload kernels
     int32_t   num_cu;
 };
+
+#define DESC_CAP (1u << 18)   // descriptors per launch: 4 GiB of payload per window
 
 extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
 {
@@ -188,7 +191,8 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     const size_t o_status = 0, o_totals = 256;
     const size_t o_sums = o_totals + 256 * sizeof(uint64_t);
     const size_t o_part = o_sums + ((c->ntile_sums * sizeof(uint64_t) + 255) & ~(size_t)255);
-    const size_t bytes = o_part + c->npartials * sizeof(Partial);
+    const size_t o_desc = (o_part + c->npartials * sizeof(Partial) + 255) & ~(size_t)255;
+    const size_t bytes = o_desc + (size_t)DESC_CAP * sizeof(ChunkDesc);
     hipError_t e = hipMalloc((void **)&c->ws, bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, bytes);
     hipDeviceProp_t prop;
@@ -203,6 +207,7 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     c->totals = (uint64_t *)(c->ws + o_totals);
     c->tile_sums = (uint64_t *)(c->ws + o_sums);
     c->partials = (Partial *)(c->ws + o_part);
+    c->desc = (ChunkDesc *)(c->ws + o_desc);
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return c;
 }
@@ -342,16 +347,22 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
 // segment copies
 // ---------------------------------------------------------------------------
 template <int W, bool SWAP, bool ENCODE>
-static int32_t launch_copy(mrpdr_ctx *c, const CopyArgs &a, const FmtDev &fmt, const ColsDev &cd, hipStream_t st)
+static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const ColsDev &cd, hipStream_t st)
 {
     // upper bound of the payload: it cannot exceed the arena or the column
-    uint64_t bound = a.wire.bytes < a.dense_cap ? a.wire.bytes : a.dense_cap;
-    uint64_t chunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
-    if (chunks == 0) return 1;
-    const uint64_t max_blocks = (uint64_t)c->num_cu * 8;
-    uint32_t grid = (uint32_t)(chunks < max_blocks ? chunks : max_blocks);
-    k_copy<W, SWAP, ENCODE><<<grid, MRPDR_TPB, 0, st>>>(a, fmt, cd);
-    LAUNCHED("k_copy");
+    const uint64_t bound = a.wire.bytes < a.dense_cap ? a.wire.bytes : a.dense_cap;
+    const uint64_t chunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
+    // data this large is touched once per kernel: keep it out of the caches
+    const bool nt = bound >= (32ull << 20);
+    for (uint64_t first = 0; first < chunks; first += DESC_CAP) {
+        const uint32_t nd = (uint32_t)((chunks - first) < DESC_CAP ? (chunks - first) : DESC_CAP);
+        a.first_chunk = first;
+        k_copy_plan<<<blocks_for(nd, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc, nd);
+        LAUNCHED("k_copy_plan");
+        if (nt) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc);
+        else    k_copy<W, SWAP, ENCODE, false><<<nd, MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc);
+        LAUNCHED("k_copy");
+    }
     return 1;
 }
 
@@ -368,6 +379,7 @@ static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, c
     a.dense_cap = cd.cap[field] * fd.width;
     a.status = c->status;
     a.field = field;
+    a.first_chunk = 0;
     if (n == 0 || a.dense_cap == 0) return 1;
     // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
     const bool sw = swap && fd.width > 1 && !ENCODE;
