@@ -129,6 +129,16 @@ void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
  * Synchronises `stream`. */
 int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
 
+/* Timing of the payload kernels, the counterpart of the reference's per-filter / per-packet
+ * timers (PerfDataMgr, src/PerfDataEvent.C; Packet::start_Timer, src/Filter.C:60-112).
+ * While enabled, every payload-kernel launch made through this ctx is bracketed by HIP
+ * events on the caller's stream (at most 4096 launches between two collects).
+ * collect synchronises the stream and returns, for [0] decode and [1] encode payload
+ * kernels, the summed elapsed milliseconds and the number of launches, then resets. */
+int32_t     mrpdr_ctx_perf_enable(mrpdr_ctx *ctx, int32_t on);
+int32_t     mrpdr_ctx_perf_collect(mrpdr_ctx *ctx, void *stream, double *ms_sum_host,
+                                   uint64_t *launches_host);
+
 /* ---- format strings ------------------------------------------------------
  * Fmt2Type (src/DataElement.C:205-297) + the " \t\n%" tokenising of
  * Packet::pdr_packet_data (src/Packet.C:608-619), done once per format instead of
@@ -143,17 +153,26 @@ int32_t     mrpdr_fmt_field_width(const mrpdr_fmt *f, int32_t field);
 int32_t     mrpdr_fmt_is_fixed(const mrpdr_fmt *f);
 /* bytes of scalars and length prefixes per packet (= data length for fixed formats) */
 uint64_t    mrpdr_fmt_fixed_bytes(const mrpdr_fmt *f);
+/* Arena phase that puts the first array/string payload of every packet on an `align`
+ * boundary (0 for scalar-only formats); pass it to mrpdr_wave_sizeof. */
+uint32_t    mrpdr_fmt_payload_phase(const mrpdr_fmt *f, uint32_t align);
 const char *mrpdr_fmt_string(const mrpdr_fmt *f);
 
 /* ---- sizing: pdr_sizeof for a whole wave -----------------------------------
  * Replaces the dry-run encode pdr_sizeof(Packet::pdr_packet_data) that
  * Packet::encode_pdr_data runs per packet (src/Packet.C:61, src/pdr_sizeof.c:120-140).
- * lens[i] = encoded data length of packet i; offsets[0..n] = exclusive prefix scan of
- * lens rounded up to `align` (1, or a power of two up to 256) -- the arena layout.
- * total_host (optional) receives offsets[n] and synchronises the stream. */
+ * lens[i] = encoded data length of packet i.  The arena layout: packet i owns a slot of
+ * round_up(phase + lens[i], align) bytes and starts `phase` bytes into it, so
+ * offsets[i] = (sum of the slots before i) + phase and offsets[n] = the arena size
+ * (align: 1 or a power of two up to 256; phase < align; align 1 / phase 0 = packed).
+ * Placement is free because the reference keeps every packet in its own malloc block;
+ * the bytes of each packet do not change.  A phase from mrpdr_fmt_payload_phase lines
+ * the array payloads up with cache lines, which the encode kernel's stores like.
+ * Scalar-only formats ignore phase.  total_host (optional) receives offsets[n] and
+ * synchronises the stream. */
 int32_t mrpdr_wave_sizeof(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
-                          uint64_t n, uint32_t align, uint64_t *lens, uint64_t *offsets,
-                          uint64_t *total_host, void *stream);
+                          uint64_t n, uint32_t align, uint32_t phase, uint64_t *lens,
+                          uint64_t *offsets, uint64_t *total_host, void *stream);
 
 /* ---- encode: Packet::encode_pdr_data for a whole wave -------------------------
  * (src/Packet.C:54-85 -> pdr_packet_data ENCODE, src/Packet.C:594-845 -> pdrmem_put*,

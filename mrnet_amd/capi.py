@@ -13,9 +13,10 @@ LIB_PATH = os.path.join(_HERE, "lib", "libmrpdr.so")
 SYMBOLS = (
     "mrpdr_version", "mrpdr_last_error", "mrpdr_local_byteorder",
     "mrpdr_ctx_create", "mrpdr_ctx_destroy", "mrpdr_ctx_status",
+    "mrpdr_ctx_perf_enable", "mrpdr_ctx_perf_collect",
     "mrpdr_fmt_compile", "mrpdr_fmt_free", "mrpdr_fmt_nfields", "mrpdr_fmt_field_type",
     "mrpdr_fmt_field_kind", "mrpdr_fmt_field_width", "mrpdr_fmt_is_fixed",
-    "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_string",
+    "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
     "mrpdr_wave_sizeof", "mrpdr_wave_encode",
     "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
     "mrpdr_header_bytes", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
@@ -55,6 +56,8 @@ def load():
         "mrpdr_ctx_create": (vp, [i32, u64]),
         "mrpdr_ctx_destroy": (None, [vp]),
         "mrpdr_ctx_status": (i32, [vp, vp, C.POINTER(u32)]),
+        "mrpdr_ctx_perf_enable": (i32, [vp, i32]),
+        "mrpdr_ctx_perf_collect": (i32, [vp, vp, C.POINTER(C.c_double), C.POINTER(u64)]),
         "mrpdr_fmt_compile": (vp, [C.c_char_p]),
         "mrpdr_fmt_free": (None, [vp]),
         "mrpdr_fmt_nfields": (i32, [vp]),
@@ -63,8 +66,9 @@ def load():
         "mrpdr_fmt_field_width": (i32, [vp, i32]),
         "mrpdr_fmt_is_fixed": (i32, [vp]),
         "mrpdr_fmt_fixed_bytes": (u64, [vp]),
+        "mrpdr_fmt_payload_phase": (u32, [vp, u32]),
         "mrpdr_fmt_string": (C.c_char_p, [vp]),
-        "mrpdr_wave_sizeof": (i32, [vp, vp, C.POINTER(Column), u64, u32, vp, vp, C.POINTER(u64), vp]),
+        "mrpdr_wave_sizeof": (i32, [vp, vp, C.POINTER(Column), u64, u32, u32, vp, vp, C.POINTER(u64), vp]),
         "mrpdr_wave_encode": (i32, [vp, vp, C.POINTER(Column), u64, C.POINTER(Wire), vp]),
         "mrpdr_wave_decode_begin": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp,
                                           C.POINTER(u64), vp]),

@@ -85,8 +85,13 @@ struct CopyArgs {
 struct ChunkDesc {
     uint64_t wire_off;     // arena offset of the wire byte that matches the chunk's first byte
     uint32_t seg;          // packet the chunk starts in
-    uint32_t len_single;   // bytes in the chunk (<= COPY_CHUNK) << 1 | 1 when inside one packet
+    uint32_t info;         // bytes in the chunk (<= COPY_CHUNK) << 3 | DESC_* flags
 };
+#define DESC_SINGLE 1u     // the chunk lies inside one packet
+#define DESC_HEAD   2u     // encode: the bytes in front of the first aligned wire piece are ours to write
+#define DESC_EXTEND 4u     // encode: the last aligned wire piece may run into the next chunk's bytes
+// a full chunk inside one packet with nothing special at either end
+#define DESC_COMMON ((COPY_CHUNK << 3) | DESC_EXTEND | DESC_SINGLE)
 
 // Position of field f's payload inside packet s: fixed part, own prefix, and the
 // payloads of the variable fields in front of it.
@@ -124,6 +129,16 @@ __device__ inline void seg_load(Seg &sg, uint64_t s, uint32_t w, const CopyArgs 
 }
 
 // One lane per chunk: locate it.
+//
+// Encode stores go to the wire, whose addresses have arbitrary alignment.  A misaligned
+// 128-bit store stream costs about 8 % of the kernel (partial cache lines at every
+// wavefront boundary), so an encode chunk stores 16-byte ALIGNED wire pieces and loads the
+// dense side misaligned instead (misaligned loads are free).  With delta = bytes from the
+// chunk's first wire byte to the next 16-byte boundary, piece k covers wire bytes
+// [delta + 16k, delta + 16k + 16).  Piece 1023 runs delta bytes into the next chunk
+// (DESC_EXTEND: allowed when those bytes are in the same packet); the delta bytes in front
+// of piece 0 were then written by the previous chunk, otherwise DESC_HEAD asks for them.
+template <bool ENCODE>
 __global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt, ColsDev cols,
                                                          ChunkDesc *desc, uint64_t ndesc)
 {
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt,
     const uint32_t w = fmt.f[a.field].width;
     const uint64_t total = a.seg_offs[a.n] * w;
     ChunkDesc d;
-    d.wire_off = 0; d.seg = 0; d.len_single = 0;
+    d.wire_off = 0; d.seg = 0; d.info = 0;
     const uint64_t cb = (a.first_chunk + k) * COPY_CHUNK;
     if (total > a.dense_cap) {
         if (k == 0) atomicOr(a.status, 1u);
@@ -142,7 +157,16 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt,
         seg_load(sg, seg_find(a.seg_offs, 0, a.n - 1, cb / w), w, a, fmt, cols);
         d.wire_off = (uint64_t)(sg.wire - a.wire.base) + (cb - sg.lo);
         d.seg = (uint32_t)sg.s;
-        d.len_single = ((uint32_t)(ce - cb) << 1) | (ce <= sg.hi ? 1u : 0u);
+        uint32_t flags = ce <= sg.hi ? DESC_SINGLE : 0u;
+        const uint32_t delta = (uint32_t)(0 - (uintptr_t)(a.wire.base + d.wire_off)) & 15u;
+        if (!ENCODE || delta == 0) {
+            flags |= DESC_EXTEND;
+        } else if (flags && ce - cb == COPY_CHUNK) {
+            if (ce + 16 <= sg.hi) flags |= DESC_EXTEND;
+            const bool prev_extends = cb >= COPY_CHUNK && cb - COPY_CHUNK >= sg.lo && cb + 16 <= sg.hi;
+            if (!prev_extends) flags |= DESC_HEAD;
+        }
+        d.info = ((uint32_t)(ce - cb) << 3) | flags;
     }
     desc[k] = d;
 }
@@ -167,33 +191,76 @@ __device__ inline void copy_elems(Seg &sg, uint64_t b, uint64_t end, const CopyA
     }
 }
 
+// What one workgroup needs to stream a chunk that lies inside one packet: kept first
+// and small so the kernel prologue is two scalar loads (arguments, descriptor).
+struct CopyFast {
+    const ChunkDesc *desc;
+    uint8_t *wire_base;
+    uint8_t *dense_base;       // column base + first_chunk * COPY_CHUNK
+};
+
 template <int W, bool SWAP, bool ENCODE, bool NT>
-__global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyArgs a, FmtDev fmt, ColsDev cols, const ChunkDesc *desc)
+__global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, FmtDev fmt, ColsDev cols)
 {
     typedef typename UIntOf<W>::type U;
-    const ChunkDesc d = desc[blockIdx.x];
-    const uint32_t len = d.len_single >> 1;
-    if (len == 0) return;
-    const uint64_t cb = (a.first_chunk + blockIdx.x) * COPY_CHUNK;
-    uint8_t *dense = a.dense + cb;
+    // Chunk order = workgroup order: the workgroups in flight sweep one contiguous window of
+    // HBM.  (Measured alternatives: a contiguous run of chunks per workgroup or per XCD is
+    // 5-8 % slower for this kernel.)
+    const uint32_t chunk = blockIdx.x;
+    // one 16-byte scalar load: {wire_off, seg | info << 32}
+    const ulonglong2 raw = reinterpret_cast<const ulonglong2 *>(fa.desc)[chunk];
+    const uint32_t info = (uint32_t)(raw.y >> 32);
+    uint8_t *dense = fa.dense_base + (uint64_t)chunk * COPY_CHUNK;
 
-    if (d.len_single & 1u) {
-        // whole chunk inside one packet: straight 128-bit streaming
-        uint8_t *wire = a.wire.base + d.wire_off;
+    if ((info | DESC_HEAD | DESC_EXTEND) == (DESC_COMMON | DESC_HEAD)) {
+        // a full chunk inside one packet (nearly all of a large-array wave): four 128-bit
+        // loads, then four stores, no branches in the decode direction
+        uint8_t *wire = fa.wire_base + raw.x;
+        // encode: shift to the aligned wire pieces (see k_copy_plan); decode: dense is aligned
+        const uint32_t delta = ENCODE ? ((uint32_t)(0 - (uintptr_t)wire) & 15u) : 0u;
+        // encode, last chunk of a packet: the last piece would run past the packet
+        const bool whole_last = !ENCODE || (info & DESC_EXTEND) || threadIdx.x != MRPDR_TPB - 1;
         u32x4 v[COPY_UNROLL];
 #pragma unroll
         for (int u = 0; u < COPY_UNROLL; u++) {
-            const uint32_t b = (u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
-            if (b + COPY_PIECE <= len) v[u] = ENCODE ? ld16<NT>(dense + b) : ld16_any<NT>(wire + b);
+            const uint32_t b = (u * MRPDR_TPB + threadIdx.x) * COPY_PIECE + delta;
+            if (u < COPY_UNROLL - 1 || whole_last) v[u] = ENCODE ? ld16_any<NT>(dense + b) : ld16_any<NT>(wire + b);
         }
 #pragma unroll
         for (int u = 0; u < COPY_UNROLL; u++) {
+            const uint32_t b = (u * MRPDR_TPB + threadIdx.x) * COPY_PIECE + delta;
+            if (u < COPY_UNROLL - 1 || whole_last) {
+                if (ENCODE) st16<NT>(wire + b, v[u]);
+                else        st16<NT>(dense + b, SWAP ? swap_elems<W>(v[u]) : v[u]);
+            }
+        }
+        if (ENCODE) {
+            if (!whole_last)
+                for (uint32_t e = COPY_CHUNK - COPY_PIECE + delta; e < COPY_CHUNK; e++) wire[e] = dense[e];
+            if ((info & DESC_HEAD) && threadIdx.x < delta) wire[threadIdx.x] = dense[threadIdx.x];
+        }
+        return;
+    }
+
+    const uint32_t len = info >> 3;
+    if (len == 0) return;
+    const uint32_t seg = (uint32_t)raw.y;
+    const uint64_t cb = (a.first_chunk + chunk) * COPY_CHUNK;
+
+    if (info & DESC_SINGLE) {
+        // a short chunk inside one packet: the last one of the column
+        uint8_t *wire = fa.wire_base + raw.x;
+#pragma unroll 1
+        for (int u = 0; u < COPY_UNROLL; u++) {
             const uint32_t b = (u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
             if (b + COPY_PIECE <= len) {
-                if (ENCODE) st16_any<NT>(wire + b, v[u]);
-                else        st16<NT>(dense + b, SWAP ? swap_elems<W>(v[u]) : v[u]);
+                if (ENCODE) st16_any<false>(wire + b, ld16<false>(dense + b));
+                else {
+                    u32x4 x = ld16_any<false>(wire + b);
+                    st16<false>(dense + b, SWAP ? swap_elems<W>(x) : x);
+                }
             } else if (b < len) {
-                for (uint32_t e = b; e < len; e += W) {            // tail of the column
+                for (uint32_t e = b; e < len; e += W) {
                     if (ENCODE) {
                         st_u<U>(wire + e, ld_u<U>(dense + e));
                     } else {
@@ -209,14 +276,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyArgs a, FmtDev fmt, Cols
 
     // chunk spans several packets: every lane locates its own piece
     const uint64_t ce = cb + len;
-    const uint64_t s_last = seg_find(a.seg_offs, d.seg, a.n - 1, (ce - 1) / W);
+    const uint64_t s_last = seg_find(a.seg_offs, seg, a.n - 1, (ce - 1) / W);
 #pragma unroll 1
     for (int u = 0; u < COPY_UNROLL; u++) {
         const uint64_t b = cb + ((uint64_t)u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
         if (b >= ce) continue;
         const uint64_t e = (b + COPY_PIECE < ce) ? b + COPY_PIECE : ce;
         Seg t;
-        seg_load(t, seg_find(a.seg_offs, d.seg, s_last, b / W), W, a, fmt, cols);
+        seg_load(t, seg_find(a.seg_offs, seg, s_last, b / W), W, a, fmt, cols);
         if (e - b == COPY_PIECE && e <= t.hi) {
             uint8_t *wp = t.wire + (b - t.lo);
             if (ENCODE) st16_any<false>(wp, ld16<false>(a.dense + b));

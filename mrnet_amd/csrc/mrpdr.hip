@@ -157,6 +157,16 @@ extern "C" int32_t mrpdr_fmt_field_width(const mrpdr_fmt *f, int32_t i)
 }
 extern "C" int32_t mrpdr_fmt_is_fixed(const mrpdr_fmt *f) { return f ? f->fixed : 0; }
 extern "C" uint64_t mrpdr_fmt_fixed_bytes(const mrpdr_fmt *f) { return f ? f->dev.fixed_bytes : 0; }
+extern "C" uint32_t mrpdr_fmt_payload_phase(const mrpdr_fmt *f, uint32_t align)
+{
+    if (!f || align == 0) return 0;
+    for (int i = 0; i < f->dev.nf; i++)
+        if (f->dev.f[i].kind != MRPDR_SCALAR) {
+            const uint32_t at = f->dev.f[i].fixed_before + prefix_bytes(f->dev.f[i].kind);
+            return (align - at % align) % align;
+        }
+    return 0;
+}
 extern "C" const char *mrpdr_fmt_string(const mrpdr_fmt *f) { return f ? f->text : ""; }
 
 // ---------------------------------------------------------------------------
@@ -174,7 +184,14 @@ struct mrpdr_ctx {
     uint64_t *totals;         // per-field totals gathered for the host
     ChunkDesc *desc;          // chunk descriptors of the payload kernels
     int32_t   num_cu;
+    // optional timing of the payload kernels (mrpdr_ctx_perf_*)
+    int32_t     perf_on;
+    hipEvent_t *perf_ev;      // PERF_SLOTS pairs
+    uint8_t    *perf_kind;    // 0 = decode payload, 1 = encode payload
+    uint32_t    perf_used;
 };
+
+#define PERF_SLOTS 4096
 
 #define DESC_CAP (1u << 18)   // descriptors per launch: 4 GiB of payload per window
 
@@ -215,6 +232,11 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
 extern "C" void mrpdr_ctx_destroy(mrpdr_ctx *c)
 {
     if (!c) return;
+    if (c->perf_ev) {
+        for (uint32_t i = 0; i < 2 * PERF_SLOTS; i++) (void)hipEventDestroy(c->perf_ev[i]);
+        free(c->perf_ev);
+        free(c->perf_kind);
+    }
     (void)hipFree(c->ws);
     free(c);
 }
@@ -224,6 +246,36 @@ extern "C" int32_t mrpdr_ctx_status(mrpdr_ctx *c, void *stream, uint32_t *status
     if (!c || !status_host) return fail("mrpdr_ctx_status: NULL argument");
     HIP_OK(hipMemcpyAsync(status_host, c->status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    return 1;
+}
+
+extern "C" int32_t mrpdr_ctx_perf_enable(mrpdr_ctx *c, int32_t on)
+{
+    if (!c) return fail("mrpdr_ctx_perf_enable: NULL ctx");
+    if (on && !c->perf_ev) {
+        c->perf_ev = (hipEvent_t *)calloc(2 * PERF_SLOTS, sizeof(hipEvent_t));
+        c->perf_kind = (uint8_t *)calloc(PERF_SLOTS, 1);
+        if (!c->perf_ev || !c->perf_kind) return fail("mrpdr_ctx_perf_enable: out of memory");
+        for (uint32_t i = 0; i < 2 * PERF_SLOTS; i++) HIP_OK(hipEventCreate(&c->perf_ev[i]));
+    }
+    c->perf_on = on ? 1 : 0;
+    c->perf_used = 0;
+    return 1;
+}
+
+extern "C" int32_t mrpdr_ctx_perf_collect(mrpdr_ctx *c, void *stream, double *ms_sum_host, uint64_t *launches_host)
+{
+    if (!c || !ms_sum_host || !launches_host) return fail("mrpdr_ctx_perf_collect: NULL argument");
+    ms_sum_host[0] = ms_sum_host[1] = 0.0;
+    launches_host[0] = launches_host[1] = 0;
+    HIP_OK(hipStreamSynchronize((hipStream_t)stream));
+    for (uint32_t i = 0; i < c->perf_used; i++) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, c->perf_ev[2 * i], c->perf_ev[2 * i + 1]));
+        ms_sum_host[c->perf_kind[i]] += ms;
+        launches_host[c->perf_kind[i]]++;
+    }
+    c->perf_used = 0;
     return 1;
 }
 
@@ -289,16 +341,17 @@ static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *
 }
 
 // exclusive scan of in[n] (rounded up to align) into out[n+1]
-static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t align, uint64_t *out, hipStream_t st)
+static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t align, uint32_t phase,
+                        uint64_t *out, hipStream_t st)
 {
     const uint32_t tiles = n ? blocks_for(n, SCAN_TILE) : 1;
     if (n) {
-        k_scan_partial<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, c->tile_sums);
+        k_scan_partial<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, phase, c->tile_sums);
         LAUNCHED("k_scan_partial");
         k_scan_top<<<1, MRPDR_TPB, 0, st>>>(c->tile_sums, tiles);
         LAUNCHED("k_scan_top");
     }
-    k_scan_final<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, c->tile_sums, out);
+    k_scan_final<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, phase, c->tile_sums, out);
     LAUNCHED("k_scan_final");
     return 1;
 }
@@ -313,11 +366,12 @@ static bool rows_path_ok(const mrpdr_fmt *f, const WireDev &w)
 // sizing
 // ---------------------------------------------------------------------------
 extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
-                                     uint64_t n, uint32_t align, uint64_t *lens, uint64_t *offsets,
-                                     uint64_t *total_host, void *stream)
+                                     uint64_t n, uint32_t align, uint32_t phase, uint64_t *lens,
+                                     uint64_t *offsets, uint64_t *total_host, void *stream)
 {
     if (!check_common("mrpdr_wave_sizeof", c, f, n)) return 0;
     if (align == 0 || align > 256 || (align & (align - 1))) return fail("mrpdr_wave_sizeof: align must be a power of two <= 256");
+    if (phase >= align) return fail("mrpdr_wave_sizeof: phase must be smaller than align");
     if (!offsets) return fail("mrpdr_wave_sizeof: NULL offsets");
     hipStream_t st = (hipStream_t)stream;
     if (f->fixed) {
@@ -335,7 +389,7 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
         k_size<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, cd, n, lens);
         LAUNCHED("k_size");
     }
-    if (!run_scan(c, lens, n, align, offsets, st)) return 0;
+    if (!run_scan(c, lens, n, align, phase, offsets, st)) return 0;
     if (total_host) {
         HIP_OK(hipMemcpyAsync(total_host, offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -357,11 +411,18 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     for (uint64_t first = 0; first < chunks; first += DESC_CAP) {
         const uint32_t nd = (uint32_t)((chunks - first) < DESC_CAP ? (chunks - first) : DESC_CAP);
         a.first_chunk = first;
-        k_copy_plan<<<blocks_for(nd, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc, nd);
+        k_copy_plan<ENCODE><<<blocks_for(nd, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc, nd);
         LAUNCHED("k_copy_plan");
-        if (nt) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc);
-        else    k_copy<W, SWAP, ENCODE, false><<<nd, MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc);
+        const bool timed = c->perf_on && c->perf_used < PERF_SLOTS;
+        if (timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
+        CopyFast fa = { c->desc, a.wire.base, a.dense + first * COPY_CHUNK };
+        if (nt) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
+        else    k_copy<W, SWAP, ENCODE, false><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
         LAUNCHED("k_copy");
+        if (timed) {
+            HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used + 1], st));
+            c->perf_kind[c->perf_used++] = ENCODE ? 1 : 0;
+        }
     }
     return 1;
 }
@@ -450,7 +511,7 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
     if (f->fixed) return 1;
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_SCALAR) continue;
-        if (!run_scan(c, cd.counts[i], n, 1, cd.offs[i], st)) return 0;
+        if (!run_scan(c, cd.counts[i], n, 1, 0, cd.offs[i], st)) return 0;
         if (totals_host)
             HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
     }

@@ -49,15 +49,17 @@ __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *total)
     return base + inc - v;
 }
 
-// Pass 1: sum of the (aligned) items of each tile.
-__global__ __launch_bounds__(MRPDR_TPB) void k_scan_partial(const uint64_t *in, uint64_t n,
-                                                            uint32_t align, uint64_t *tile_sums)
+// Every item occupies a slot of round_up(phase + item, align) bytes and starts `phase`
+// bytes into its slot (phase = 0, align = 1: a plain exclusive scan).
+// Pass 1: sum of the slots of each tile.
+__global__ __launch_bounds__(MRPDR_TPB) void k_scan_partial(const uint64_t *in, uint64_t n, uint32_t align,
+                                                            uint32_t phase, uint64_t *tile_sums)
 {
     const uint64_t first = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
     uint64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++)
-        if (first + k < n) s += round_up_pow2(in[first + k], align);
+        if (first + k < n) s += round_up_pow2(in[first + k] + phase, align);
     uint64_t total;
     block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
@@ -78,8 +80,8 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_top(uint64_t *tile_sums, uin
 }
 
 // Pass 3: offsets[i] = prefix of tile + scan inside the tile; offsets[n] = grand total.
-__global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, uint64_t n,
-                                                          uint32_t align, const uint64_t *tile_prefix,
+__global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, uint64_t n, uint32_t align,
+                                                          uint32_t phase, const uint64_t *tile_prefix,
                                                           uint64_t *out)
 {
     const uint64_t first = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
@@ -87,14 +89,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, ui
     uint64_t s = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
-        v[k] = first + k < n ? round_up_pow2(in[first + k], align) : 0;
+        v[k] = first + k < n ? round_up_pow2(in[first + k] + phase, align) : 0;
         s += v[k];
     }
     uint64_t total;
     uint64_t run = tile_prefix[blockIdx.x] + block_exclusive_scan(s, &total);
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
-        if (first + k < n) out[first + k] = run;
+        if (first + k < n) out[first + k] = run + phase;
         run += v[k];
         if (first + k + 1 == n) out[n] = run;
     }

@@ -241,11 +241,11 @@ class Codec:
         return out
 
     # ---- sizing (pdr_sizeof over the wave) ---------------------------------------
-    def sizeof(self, fmt, cols, n, align=1, want_total=True):
-        lens = self.empty(n, torch.int64)
-        offsets = self.empty(n + 1, torch.int64)
+    def sizeof(self, fmt, cols, n, align=1, phase=0, want_total=True, lens=None, offsets=None):
+        lens = self.empty(n, torch.int64) if lens is None else lens
+        offsets = self.empty(n + 1, torch.int64) if offsets is None else offsets
         total = C.c_uint64(0)
-        ok = self._lib.mrpdr_wave_sizeof(self.handle, fmt.handle, _c_columns(cols), n, align,
+        ok = self._lib.mrpdr_wave_sizeof(self.handle, fmt.handle, _c_columns(cols), n, align, phase,
                                          _ptr(lens), _ptr(offsets),
                                          C.byref(total) if want_total else None, _stream())
         _check(ok, "mrpdr_wave_sizeof")
@@ -258,7 +258,10 @@ class Codec:
                                          C.byref(w), _stream())
         _check(ok, "mrpdr_wave_encode")
 
-    def encode(self, fmt, cols, n, align=1, packed=None):
+    def payload_phase(self, fmt, align):
+        return int(self._lib.mrpdr_fmt_payload_phase(fmt.handle, align))
+
+    def encode(self, fmt, cols, n, align=1, packed=None, phase=0):
         """Encode a wave.  Fixed formats default to the packed layout (no offsets array)."""
         if packed is None:
             packed = fmt.is_fixed
@@ -269,7 +272,7 @@ class Codec:
             wire = WireWave(torch.zeros(max(n * stride, 1), dtype=torch.uint8, device=self.device),
                             n, None, None, stride)
         else:
-            lens, offsets, total = self.sizeof(fmt, cols, n, align)
+            lens, offsets, total = self.sizeof(fmt, cols, n, align, phase)
             wire = WireWave(torch.zeros(max(total, 1), dtype=torch.uint8, device=self.device),
                             n, offsets, lens, 0)
         self.encode_into(fmt, cols, wire)
@@ -317,6 +320,17 @@ class Codec:
         s = C.c_uint32(0)
         _check(self._lib.mrpdr_ctx_status(self.handle, _stream(), C.byref(s)), "mrpdr_ctx_status")
         return s.value
+
+    def perf_enable(self, on=True):
+        _check(self._lib.mrpdr_ctx_perf_enable(self.handle, int(on)), "mrpdr_ctx_perf_enable")
+
+    def perf_collect(self):
+        """{'decode': (ms_sum, launches), 'encode': (ms_sum, launches)} of the payload kernels
+        since the last collect (HIP events on the stream the kernels ran on)."""
+        ms = (C.c_double * 2)()
+        cnt = (C.c_uint64 * 2)()
+        _check(self._lib.mrpdr_ctx_perf_collect(self.handle, _stream(), ms, cnt), "mrpdr_ctx_perf_collect")
+        return {"decode": (ms[0], cnt[0]), "encode": (ms[1], cnt[1])}
 
     # ---- headers ---------------------------------------------------------------------
     def encode_headers(self, fmt, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,

@@ -150,19 +150,21 @@ def wave_sizeof(fmt, cols, n):
     return lens
 
 
-def scan_offsets(lens, align=1):
-    """Exclusive scan of lens rounded up to `align` (the arena layout rule)."""
+def scan_offsets(lens, align=1, phase=0):
+    """The arena layout rule: packet i owns a slot of round_up(phase + len, align) bytes and
+    starts `phase` bytes into it; offsets[n] is the arena size."""
     a = np.uint64(align)
-    padded = (lens.astype(np.uint64) + (a - np.uint64(1))) // a * a
+    slots = (lens.astype(np.uint64) + np.uint64(phase) + (a - np.uint64(1))) // a * a
     offs = np.zeros(len(lens) + 1, dtype=np.uint64)
-    np.cumsum(padded, out=offs[1:])
+    np.cumsum(slots, out=offs[1:])
+    offs[:-1] += np.uint64(phase)
     return offs
 
 
-def wave_encode(fmt, cols, n, align=1):
+def wave_encode(fmt, cols, n, align=1, phase=0):
     """Returns (arena u8[], offsets u64[n+1], lens u64[n]); padding bytes are zero."""
     lens = wave_sizeof(fmt, cols, n)
-    offs = scan_offsets(lens, align)
+    offs = scan_offsets(lens, align, phase)
     arena = np.zeros(int(offs[-1]), dtype=np.uint8)
     keep = []
     lens2 = np.zeros(n, dtype=np.uint64)

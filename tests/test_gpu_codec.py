@@ -176,7 +176,9 @@ def test_reference_test_values_round_trip(codec, golden):
 
 
 @pytest.mark.parametrize("fmt_s,n,maxc", [("%af", 37, 20000), ("%auc", 3000, 600), ("%ald", 9, 9000),
-                                          ("%ahd %s %alf", 300, 700), ("%auc", 70000, 3)])
+                                          ("%ahd %s %alf", 300, 700), ("%auc", 70000, 3),
+                                          ("%s %ald %c %af", 40, 9000), ("%c %auc %hd %ahd", 20, 100000),
+                                          ("%hd %s %af", 64, 16384)])
 def test_segments_crossing_chunks(codec, fmt_s, n, maxc):
     """Arrays longer and shorter than the 16 KiB streaming chunk, odd alignments."""
     ocols = make_wave(fmt_s, n, seed=n, max_count=maxc)
@@ -185,6 +187,25 @@ def test_segments_crossing_chunks(codec, fmt_s, n, maxc):
     assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
     be = to_sender_order(fmt_s, arena, offs, lens)
     dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, be, offs, lens), W.BIGENDIAN)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+@pytest.mark.parametrize("fmt_s,n,maxc,align", [("%af", 33, 9000, 128), ("%d %s %ald", 100, 300, 64),
+                                                 ("%auc %af", 50, 5000, 256), ("%af", 5, 3, 16)])
+def test_arena_phase_layout(codec, fmt_s, n, maxc, align):
+    """Slots of `align` bytes with the first payload of every packet on an align boundary:
+    same packet bytes, different placement."""
+    ocols = make_wave(fmt_s, n, seed=align + n, max_count=maxc)
+    fmt = W.Format(fmt_s)
+    phase = codec.payload_phase(fmt, align)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align, phase=phase)
+    first_var = [i for i, k in enumerate(fmt.kinds) if k != W.SCALAR][0]
+    before = sum(fmt.widths[i] for i in range(first_var)) + (4 if fmt.kinds[first_var] == W.STRING else 8)
+    assert all((int(o) + before) % align == 0 for o in offs[:-1])
+    wire = codec.encode(fmt, dev_cols(codec, fmt, ocols), n, align=align, phase=phase)
+    assert np.array_equal(W.Codec.to_numpy(wire.offsets).view(np.uint64), offs)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    dcols, ok = codec.decode(fmt, wire)
     assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
 
 

@@ -45,6 +45,15 @@ template <int U> __global__ void k_mkdesc(Desc *d, uint64_t nch, uint64_t mis)
     if (c < nch) { d[c].wire_off = c * 256ull * 16 * U + mis; d[c].seg = (uint32_t)c; d[c].single = 1; }
 }
 
+__global__ void k_fill_random(uint32_t *p, uint64_t n)
+{
+    uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    for (; i < n; i += (uint64_t)gridDim.x * 256) {
+        uint64_t z = i * 0x9E3779B97F4A7C15ull; z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27;
+        p[i] = (uint32_t)(z >> 16);
+    }
+}
+
 template <typename F> static float timeit(F f, int reps)
 {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -65,11 +74,13 @@ int main()
 #define RUN(name, U, NTL, NTS, DESC, grid) { \
     uint64_t nch = bytes / (4096ull * U); \
     if (DESC) { k_mkdesc<U><<<(nch + 255) / 256, 256>>>(desc, nch, 8); CK(hipDeviceSynchronize()); } \
-    int g = (grid) == 0 ? (int)nch : (grid); \
-    float ms = timeit([&] { k_gs<U, NTL, NTS, DESC><<<g, 256>>>(in, out, bytes, desc); }, 20); \
-    printf("%-36s U%d grid %6d  %.4f ms  %7.1f GB/s\n", name, U, g, ms, 2.0 * bytes / ms / 1e6); }
-    int grids[] = {2048, 4096, 8192, 16384, 32768, 0};
-    for (int g : grids) {
+    int gg = (grid) == 0 ? (int)nch : (grid); \
+    float ms = timeit([&] { k_gs<U, NTL, NTS, DESC><<<gg, 256>>>(in, out, bytes, desc); }, 20); \
+    printf("%-36s U%d grid %6d  %.4f ms  %7.1f GB/s\n", name, U, gg, ms, 2.0 * bytes / ms / 1e6); }
+    for (int pass = 0; pass < 2; pass++) {
+        if (pass == 1) { k_fill_random<<<4096, 256>>>((uint32_t *)in, bytes / 4); CK(hipDeviceSynchronize()); printf("-- random data --\n"); }
+        else printf("-- constant data --\n");
+        const int g = 0;
         RUN("nt ld+st", 1, true, true, false, g);
         RUN("nt ld+st", 2, true, true, false, g);
         RUN("nt ld+st", 4, true, true, false, g);
