@@ -344,6 +344,11 @@ static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *
 static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t align, uint32_t phase,
                         uint64_t *out, hipStream_t st)
 {
+    if (n <= SCAN1_MAX_N) {
+        k_scan_single<false><<<1, SCAN1_TPB, 0, st>>>(in, FmtDev(), ColsDev(), n, align, phase, nullptr, out);
+        LAUNCHED("k_scan_single");
+        return 1;
+    }
     const uint32_t tiles = n ? blocks_for(n, SCAN_TILE) : 1;
     if (n) {
         k_scan_partial<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, phase, c->tile_sums);
@@ -385,11 +390,15 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
     if (n && !lens) return fail("mrpdr_wave_sizeof: NULL lens");
     ColsDev cd;
     if (!fill_cols("mrpdr_wave_sizeof", f, cols, n, false, &cd)) return 0;
-    if (n) {
+    if (n <= SCAN1_MAX_N) {
+        // sizing and scan fused in one launch
+        k_scan_single<true><<<1, SCAN1_TPB, 0, st>>>(nullptr, f->dev, cd, n, align, phase, lens, offsets);
+        LAUNCHED("k_scan_single");
+    } else {
         k_size<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, cd, n, lens);
         LAUNCHED("k_size");
+        if (!run_scan(c, lens, n, align, phase, offsets, st)) return 0;
     }
-    if (!run_scan(c, lens, n, align, phase, offsets, st)) return 0;
     if (total_host) {
         HIP_OK(hipMemcpyAsync(total_host, offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));

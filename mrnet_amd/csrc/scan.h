@@ -29,17 +29,19 @@ __device__ inline uint64_t wave_inclusive_scan(uint64_t v)
     return v;
 }
 
-// Workgroup-wide exclusive scan of one value per thread; *total = sum over the group.
+// Workgroup-wide exclusive scan of one value per thread (NW wavefronts per workgroup);
+// *total = sum over the group.
+template <int NW = MRPDR_TPB / 64>
 __device__ inline uint64_t block_exclusive_scan(uint64_t v, uint64_t *total)
 {
-    __shared__ uint64_t wave_sums[MRPDR_TPB / 64];
+    __shared__ uint64_t wave_sums[NW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint64_t inc = wave_inclusive_scan(v);
     if (lane == 63) wave_sums[wave] = inc;
     __syncthreads();
     uint64_t base = 0, sum = 0;
 #pragma unroll
-    for (int w = 0; w < MRPDR_TPB / 64; w++) {
+    for (int w = 0; w < NW; w++) {
         uint64_t s = wave_sums[w];
         if (w < wave) base += s;
         sum += s;
@@ -101,6 +103,52 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, ui
         if (first + k + 1 == n) out[n] = run;
     }
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+// Small waves: the whole scan in ONE launch by one 1024-lane workgroup that walks the
+// items tile by tile with a running carry.  With SIZED the item is not read from `in`
+// but computed from the wave's count columns -- the pdr_sizeof dry run of every packet
+// (src/pdr_sizeof.c:120-140) -- and also stored to lens[].
+#define SCAN1_TPB 1024
+#define SCAN1_MAX_N (4u * SCAN1_TPB * SCAN_IPT)     // above this the three-pass scan is faster
+
+template <bool SIZED>
+__global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, FmtDev fmt, ColsDev cols,
+                                                           uint64_t n, uint32_t align, uint32_t phase,
+                                                           uint64_t *lens, uint64_t *out)
+{
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n; base += (uint64_t)SCAN1_TPB * SCAN_IPT) {
+        const uint64_t first = base + (uint64_t)threadIdx.x * SCAN_IPT;
+        uint64_t v[SCAN_IPT];
+        uint64_t s = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_IPT; k++) {
+            uint64_t item = 0;
+            if (first + k < n) {
+                if (SIZED) {
+                    item = fmt.fixed_bytes;
+                    for (int f = 0; f < fmt.nf; f++)
+                        if (fmt.f[f].kind != MRPDR_SCALAR) item += cols.counts[f][first + k] * (uint64_t)fmt.f[f].width;
+                    lens[first + k] = item;
+                } else {
+                    item = in[first + k];
+                }
+                item = round_up_pow2(item + phase, align);
+            }
+            v[k] = item;
+            s += item;
+        }
+        uint64_t total;
+        uint64_t run = carry + block_exclusive_scan<SCAN1_TPB / 64>(s, &total);
+#pragma unroll
+        for (int k = 0; k < SCAN_IPT; k++) {
+            if (first + k < n) out[first + k] = run + phase;
+            run += v[k];
+        }
+        carry += total;
+    }
+    if (threadIdx.x == 0) out[n] = carry;
 }
 
 // Packed layout of a fixed-length format: closed form, no scan needed.

@@ -1,0 +1,51 @@
+"""Multi-GPU side of the wave codec: one process per GPU, torch.distributed (RCCL on GPUs).
+
+Packets of a wave are independent, so encode/decode shard by packet range with no
+collective at all.  The only exchange is the filter result: every rank reduces its shard
+with the declared tree shape, the 16-byte results are all-gathered, and the last tree level
+(fan-in = number of ranks, rank order) is folded on every rank.  An ordered fold rather than
+an all-reduce sum: float Sum and every Avg depend on the fold order
+(src/FilterDefinitions.C:1925-2040).
+"""
+import torch
+import torch.distributed as dist
+
+from . import wave as W
+
+
+def shard_range(n, rank, world):
+    """Contiguous packet range [lo, hi) of `rank`: [rank*n/world, (rank+1)*n/world)."""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def gather_results(result, result_ok, group=None):
+    """all_gather the per-rank filter results.  result: uint8[16], result_ok: int32[1] (on the
+    device with RCCL, on the host with gloo).  Returns (uint8[G,16], int32[G]) in rank order."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return result.view(1, 16).clone(), result_ok.view(1).clone()
+    packed = torch.zeros(20, dtype=torch.uint8, device=result.device)
+    packed[:16] = result
+    packed[16:20] = result_ok.view(torch.uint8)
+    out = [torch.empty_like(packed) for _ in range(world)]
+    dist.all_gather(out, packed, group=group)
+    rows = torch.stack(out)
+    return rows[:, :16].contiguous(), rows[:, 16:20].contiguous().view(torch.int32).view(-1)
+
+
+def combine_results(codec, op, dtype, elem_bytes, rows, oks):
+    """Last tree level: fold the present per-rank results in rank order on the device.
+    rows: uint8[G,16] (value, then the int32 count for AVG), oks: int32[G]."""
+    present = rows[oks != 0].contiguous()
+    g = present.shape[0]
+    base = present.data_ptr() if g else None
+    return codec.filter_raw(op, dtype, base, 16, (base + elem_bytes) if g else None, 16, g, 0,
+                            W.SHAPE_FLAT)
+
+
+def filter_wire_sharded(codec, op, fmt, wire, sender_bo=W.LITTLEENDIAN, group=None):
+    """tfilter_* over a wave whose packets are spread over the ranks of `group`; `wire` is this
+    rank's shard (packed fixed-format layout).  Every rank returns the same (result, ok)."""
+    res, ok = codec.filter_wire(op, fmt, wire, sender_bo, W.SHAPE_TREE)
+    rows, oks = gather_results(res, ok, group)
+    return combine_results(codec, op, fmt.types[0], fmt.widths[0], rows, oks)

@@ -169,3 +169,38 @@ def test_fused_decode_filter_on_the_wire(codec, shape):
                     {"type": O.INT32_T, "values": np.array([ref[1]], np.int32)}]
         out_arena, _, _ = O.wave_encode("%lf %d", out_cols, 1)
         assert res.cpu().numpy()[:12].tobytes() == out_arena.tobytes()
+
+
+@pytest.mark.parametrize("opname,op", OPS)
+def test_sharded_wave_combine(codec, opname, op):
+    """A 1M-packet '%lf %d' wave in 8 packet ranges (BASELINE config 5 shape): per-range tree
+    result on the GPU, then the rank-ordered last level -- against the oracle doing the same."""
+    from mrnet_amd import dist as D
+    n, world = 1 << 20, 8
+    v = values_for(np.float64, n, 55, op)
+    c = counts_for(n, 55)
+    cols = [{"type": O.DOUBLE_T, "values": v}, {"type": O.INT32_T, "values": c}]
+    arena, offs, lens = O.wave_encode("%lf %d", cols, n)
+    fmt = W.Format("%lf %d")
+    rows, oks, ref_v, ref_c = [], [], [], []
+    for r in range(world):
+        lo, hi = D.shard_range(n, r, world)
+        wire = W.WireWave(codec.to_device(arena[lo * 12:hi * 12]), hi - lo, None, None, 12)
+        res, ok = codec.filter_raw(op, O.DOUBLE_T, wire.arena.data_ptr(), 12, wire.arena.data_ptr() + 8, 12,
+                                   hi - lo, 0, W.SHAPE_TREE)
+        rows.append(res.clone()); oks.append(ok.clone())
+        ref = O.filter_tree(op, O.DOUBLE_T, v[lo:hi], c[lo:hi] if op == O.AVG else None, W.TREE_FANINS)
+        ref_v.append(ref[0]); ref_c.append(ref[1] if op == O.AVG else 1)
+    res, ok = D.combine_results(codec, op, W.DataType.DOUBLE_T, 8, torch.stack(rows), torch.cat(oks))
+    got = W.result_value(res, ok, np.dtype(np.float64), op)
+    want = O.filter_flat(op, O.DOUBLE_T, np.array(ref_v), np.array(ref_c, np.int32) if op == O.AVG else None)
+    assert np.asarray(got[0]).tobytes() == np.asarray(want[0]).tobytes()
+    if op == O.AVG:
+        assert got[1] == want[1] == int(c.sum())
+    # single-process group: the sharded entry point degenerates to the local tree + one more level
+    wire = W.WireWave(codec.to_device(arena), n, None, None, 12)
+    res1, ok1 = D.filter_wire_sharded(codec, op, fmt, wire) if op == O.AVG else (None, None)
+    if op == O.AVG:
+        whole = O.filter_tree(op, O.DOUBLE_T, v, c, W.TREE_FANINS)
+        last = O.filter_flat(op, O.DOUBLE_T, np.array([whole[0]]), np.array([whole[1]], np.int32))
+        assert np.asarray(W.result_value(res1, ok1, np.dtype(np.float64), op)[0]).tobytes() == np.asarray(last[0]).tobytes()
