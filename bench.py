@@ -194,9 +194,44 @@ def small_wave_extras(codec):
             codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
                              n5, 0, W.SHAPE_TREE, r, rok)
     out["c5_shard_us_per_wave"] = round(time_call(c5, 200) * 1e6, 2)
+    out.update(mixed_wave_extra(codec))
     assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
     assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
     return out
+
+
+def mixed_wave_extra(codec):
+    """Config 4: 65,536 packets '%d %uld %lf %s %auc' with variable-length fields (string length
+    geometric, mean 12, max 255; byte array length uniform in [0, 512])."""
+    n = 65536
+    dev = codec.device
+    fmt = W.Format("%d %uld %lf %s %auc")
+    rng = np.random.default_rng(4)
+    slen = np.minimum(rng.geometric(1.0 / 12.0, n), 255).astype(np.uint64) + 1      # strlen+1
+    alen = rng.integers(0, 513, n).astype(np.uint64)
+    sbody = rng.integers(33, 127, int(slen.sum()), dtype=np.uint8)
+    sbody[np.cumsum(slen).astype(np.int64) - 1] = 0
+    cols = codec.columns_from_numpy(fmt, [
+        rng.integers(-2**31, 2**31, n).astype(np.int32), rng.integers(0, 2**63, n).astype(np.uint64),
+        rng.uniform(-1e6, 1e6, n), (slen, sbody), (alen, rng.integers(0, 256, int(alen.sum()), dtype=np.uint8))])
+    lens, offs, total = codec.sizeof(fmt, cols, n, 16, 0)
+    wire = W.WireWave(torch.zeros(total, dtype=torch.uint8, device=dev), n, offs, lens, 0)
+    dcols = codec.alloc_columns(fmt, n, capacities=[0, 0, 0, int(slen.sum()), int(alen.sum())])
+    ok = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def enc():
+        codec.sizeof(fmt, cols, n, 16, 0, want_total=False, lens=lens, offsets=offs)
+        codec.encode_into(fmt, cols, wire)
+
+    def dec():
+        codec.decode_into(fmt, wire, dcols, ok)
+    t_enc, t_dec = time_call(enc, 50), time_call(dec, 50)
+    assert bool(ok.all()) and torch.equal(dcols[4].values, cols[4].values) and torch.equal(dcols[3].values, cols[3].values)
+    data = int(lens.sum().item())
+    decoded = 20 * n + int(slen.sum()) + int(alen.sum())
+    nbytes = 2 * (data + decoded) + 8 * (n + 1)
+    return {"c4_encode_us": round(t_enc * 1e6, 1), "c4_decode_us": round(t_dec * 1e6, 1),
+            "c4_gbps": round(nbytes / (t_enc + t_dec) / 1e9, 1), "c4_wire_mib": round(data / 2**20, 1)}
 
 
 def time_call(fn, reps):

@@ -1,0 +1,191 @@
+"""`Packet` and the built-in transformation filters of the reference, for a wave at a time.
+
+A PacketWave is what `std::vector<PacketPtr>` is to a filter in the reference
+(src/Filter.h:64-68): n packets that share a stream id, a tag and a format string.  Method
+names, argument meaning and error behaviour follow include/mrnet/Packet.h:41-118 and
+src/Packet.C:
+
+  * constructing from values encodes the data at once (src/Packet.C:137-165 -> encode_pdr_data);
+    the header is encoded lazily, when it is first asked for (src/Message.C:288-292)
+  * constructing from received buffers decodes the header at once and the data lazily, on the
+    first unpack / [] (src/Packet.C:277-295, 343-367)
+  * unpack(fmt) returns -1 when fmt differs from the packet's format string (strcmp,
+    src/Packet.C:527-532)
+  * a decode failure sets has_Error() and ok[i] = 0 for the packets concerned
+    (error(ERR_PACKING), src/Packet.C:122-124)
+  * tfilter_Sum / Max / Min / Avg return one packet with the stream id and tag of the first
+    input packet and the same format (src/FilterDefinitions.C:151-221)
+"""
+import numpy as np
+import torch
+
+from . import wave as W
+
+
+class PacketWave:
+    def __init__(self, codec, stream_id, tag, fmt, columns, n=None, src_rank=W.UNKNOWN_RANK,
+                 src_ranks=None, align=1, phase=0):
+        """API constructor: packets from per-field columns (numpy or device Columns)."""
+        self.codec = codec
+        self.fmt = fmt if isinstance(fmt, W.Format) else W.Format(fmt)
+        self.stream_id, self.tag, self.src_rank, self.src_ranks = stream_id, tag, src_rank, src_ranks
+        self.inlet_rank = W.UNKNOWN_RANK
+        self._error = False
+        if columns and not isinstance(columns[0], W.Column):
+            columns = codec.columns_from_numpy(self.fmt, columns)
+        self.columns = list(columns)
+        if n is None:
+            first = self.columns[0] if self.columns else None
+            n = 0 if first is None else (first.counts.numel() if first.counts is not None
+                                         else first.values.numel())
+        self.n = n
+        self.ok = None
+        self._decoded = True
+        self._hdrs = None
+        self.byteorder = W.LITTLEENDIAN
+        self.wire = codec.encode(self.fmt, self.columns, n, align=align, phase=phase)   # encode_pdr_data
+
+    @classmethod
+    def from_buffers(cls, codec, fmt, n, hdrs, hdr_stride, wire, inlet_rank=W.UNKNOWN_RANK):
+        """Receive-side constructor: Packet(hdr_len, hdr, buf_len, buf, inlet_rank)."""
+        self = cls.__new__(cls)
+        self.codec = codec
+        self.fmt = fmt if isinstance(fmt, W.Format) else W.Format(fmt)
+        self.n, self.wire, self.inlet_rank = n, wire, inlet_rank
+        self._hdrs, self._hdr_stride = hdrs, hdr_stride
+        self.columns, self.ok, self._decoded, self._error = None, None, False, False
+        h = codec.decode_headers(self.fmt, n, hdrs, stride=hdr_stride)            # decode_pdr_header
+        self.header = h
+        self.src_ranks = h["src_rank"]
+        self.src_rank = W.UNKNOWN_RANK
+        if n:
+            self.stream_id = int(h["stream_id"][0].item()) & 0xFFFFFFFF
+            self.tag = int(h["tag"][0].item())
+            bo = h["byteorder"]
+            self.byteorder = int(bo[0].item())
+            if not bool(h["ok"].all()) or not bool((bo == bo[0]).all()):
+                self._error = True          # foreign format or mixed byte orders in one wave
+        else:
+            self.stream_id, self.tag, self.byteorder = 0xFFFFFFFF, -1, W.LITTLEENDIAN
+        return self
+
+    # ---- accessors (include/mrnet/Packet.h:48-74) ----------------------------------
+    def get_Tag(self):
+        return self.tag
+
+    def get_StreamId(self):
+        return self.stream_id
+
+    def get_FormatString(self):
+        return self.fmt.text
+
+    def get_InletNodeRank(self):
+        return self.inlet_rank
+
+    def get_SourceRank(self):
+        return self.src_ranks if self.src_ranks is not None else self.src_rank
+
+    def get_Buffer(self):
+        return self.wire
+
+    def get_BufferLen(self):
+        return self.wire.lens if self.wire.lens is not None else self.fmt.fixed_bytes
+
+    def get_Header(self):
+        if self._hdrs is None:                                                   # encode_pdr_header
+            self._hdrs, self._hdr_stride = self.codec.encode_headers(
+                self.fmt, self.n, stream_id=self.stream_id, tag=self.tag, src_rank=self.src_rank,
+                src_ranks=self.src_ranks)
+        return self._hdrs
+
+    def get_HeaderLen(self):
+        return self.fmt.header_bytes
+
+    def has_Error(self):
+        return self._error
+
+    def size(self):
+        return self.n
+
+    # ---- decode ------------------------------------------------------------------------
+    def _decode(self):
+        if not self._decoded:
+            self.columns, self.ok = self.codec.decode(self.fmt, self.wire, self.byteorder)
+            self._decoded = True
+            if self.n and not bool(self.ok.all()):
+                self._error = True
+
+    def unpack(self, fmt):
+        """Columns of the wave, or -1 when fmt is not the packets' format string."""
+        self._decode()
+        if fmt is None or fmt != self.fmt.text:
+            return -1
+        return self.columns
+
+    def __getitem__(self, i):
+        self._decode()
+        return self.columns[i] if 0 <= i < len(self.columns) else None
+
+    def values(self, i, dtype=None):
+        """Host copy of field i (scalar: T[n]; array/string: (counts, values))."""
+        c = self[i]
+        dt = self.fmt.np_dtype(i) if dtype is None else dtype
+        if self.fmt.kinds[i] == W.SCALAR:
+            return W.Codec.to_numpy(c.values).view(dt)[: self.n]
+        counts = W.Codec.to_numpy(c.counts).view(np.uint64)
+        total = int(W.Codec.to_numpy(c.offs).view(np.uint64)[self.n])
+        return counts, (W.Codec.to_numpy(c.values).view(dt)[:total] if total else np.zeros(0, dt))
+
+
+_SCALAR_FORMATS = {"%c": W.DataType.CHAR_T, "%uc": W.DataType.UCHAR_T, "%hd": W.DataType.INT16_T,
+                   "%uhd": W.DataType.UINT16_T, "%d": W.DataType.INT32_T, "%ud": W.DataType.UINT32_T,
+                   "%ld": W.DataType.INT64_T, "%uld": W.DataType.UINT64_T, "%f": W.DataType.FLOAT_T,
+                   "%lf": W.DataType.DOUBLE_T}
+
+
+def _run_filter(op, ipackets, shape):
+    codec, fmt = ipackets.codec, ipackets.fmt
+    if ipackets.n == 0 or ipackets.has_Error():
+        return None
+    if op == W.TFILTER_AVG:
+        # "<T> %d" exactly, as tfilter_Avg compares the whole string (src/FilterDefinitions.C:525-544)
+        parts = fmt.text.split(" ")
+        if len(parts) != 2 or parts[1] != "%d" or parts[0] not in _SCALAR_FORMATS:
+            return None
+    elif fmt.text not in _SCALAR_FORMATS:
+        return None             # the reference logs "invalid packet type" and emits nothing
+    wire = ipackets.wire
+    if wire.offsets is None:
+        res, ok = codec.filter_wire(op, fmt, wire, ipackets.byteorder, shape)      # fused decode
+    else:
+        cols = ipackets.unpack(fmt.text)
+        cnt = cols[1].values if op == W.TFILTER_AVG else None
+        res, ok = codec.filter_columns(op, fmt.types[0], cols[0].values, cnt, shape)
+    if int(ok.item()) == 0:
+        return None             # e.g. an Avg whose counts sum to zero: nothing is emitted
+    out = PacketWave.__new__(PacketWave)
+    out.codec, out.fmt, out.n = codec, fmt, 1
+    out.stream_id, out.tag = ipackets.get_StreamId(), ipackets.get_Tag()
+    out.src_rank, out.src_ranks, out.inlet_rank = W.UNKNOWN_RANK, None, W.UNKNOWN_RANK
+    out._hdrs, out._error, out.byteorder = None, False, W.LITTLEENDIAN
+    # the 16 result bytes ARE the encoded data of the output packet
+    out.wire = W.WireWave(res, 1, None, None, fmt.fixed_bytes)
+    out.columns, out.ok, out._decoded = None, None, False
+    out.result_ok = ok
+    return out
+
+
+def tfilter_Sum(ipackets, shape=W.SHAPE_TREE):
+    return _run_filter(W.TFILTER_SUM, ipackets, shape)
+
+
+def tfilter_Max(ipackets, shape=W.SHAPE_TREE):
+    return _run_filter(W.TFILTER_MAX, ipackets, shape)
+
+
+def tfilter_Min(ipackets, shape=W.SHAPE_TREE):
+    return _run_filter(W.TFILTER_MIN, ipackets, shape)
+
+
+def tfilter_Avg(ipackets, shape=W.SHAPE_TREE):
+    return _run_filter(W.TFILTER_AVG, ipackets, shape)

@@ -202,6 +202,8 @@ class Codec:
     def to_device(self, a):
         """numpy -> device tensor holding the same bytes (unsigned kept as signed)."""
         a = np.ascontiguousarray(a)
+        if not a.flags.writeable:
+            a = a.copy()
         if a.dtype.kind == "u" and a.dtype.itemsize > 1:
             a = a.view(np.dtype("i%d" % a.dtype.itemsize))
         return torch.from_numpy(a).to(self.device)

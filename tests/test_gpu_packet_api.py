@@ -1,0 +1,141 @@
+"""The reference's own end-to-end tests, replayed on the wave API: tests/test_basic_FE.C
+(every scalar type and the alltypes packet, packed by the back-ends, unpacked by the
+front-end), tests/test_arrays_FE.C (ARRAY_LEN elements, memcmp) and
+tests/test_NativeFilters_FE.C (TFILTER_SUM of one constant per back-end)."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+from mrnet_amd.packet import PacketWave, tfilter_Avg, tfilter_Max, tfilter_Min, tfilter_Sum  # noqa: E402
+
+TOK_DTYPE = {"c": np.int8, "uc": np.uint8, "hd": np.int16, "uhd": np.uint16, "d": np.int32,
+             "ud": np.uint32, "ld": np.int64, "uld": np.uint64, "f": np.float32, "lf": np.float64}
+PROT_BASIC = W.FIRST_APPLICATION_TAG + 1
+
+
+def received(codec, sent):
+    """What the front-end holds after Message::recv: header and data buffers of the wave."""
+    return PacketWave.from_buffers(codec, sent.get_FormatString(), sent.size(), sent.get_Header(),
+                                   sent.get_HeaderLen(), sent.get_Buffer(), inlet_rank=0)
+
+
+def string_col(s, n):
+    b = np.frombuffer(s.encode() + b"\0", np.uint8)
+    return np.full(n, b.size, np.uint64), np.tile(b, n)
+
+
+@pytest.mark.parametrize("num_backends", [1, 4, 16])
+def test_basic_scalar_round_trips(codec, golden, num_backends):
+    """tests/test_basic_FE.C: send_val -17 / 17 / -17.234f / 17.3421 per type, echo, unpack, compare."""
+    vals = {"c": -17, "uc": 17, "hd": -17, "uhd": 17, "d": -17, "ud": 17, "ld": -17, "uld": 17,
+            "f": -17.234, "lf": 17.3421}
+    for tok, v in vals.items():
+        fmt = "%" + tok
+        col = np.full(num_backends, v, TOK_DTYPE[tok])
+        sent = PacketWave(codec, W.USER_STRM_BASE_ID, PROT_BASIC, fmt, [col],
+                          src_ranks=codec.to_device(np.arange(num_backends, dtype=np.uint32)))
+        got = received(codec, sent)
+        assert not got.has_Error()
+        assert got.get_StreamId() == W.USER_STRM_BASE_ID and got.get_Tag() == PROT_BASIC
+        assert got.get_FormatString() == fmt
+        assert got.unpack("%d %d") == -1                   # format mismatch, src/Packet.C:527-532
+        assert got.unpack(fmt) != -1
+        assert np.array_equal(got.values(0), col), tok
+        assert np.array_equal(W.Codec.to_numpy(got.get_SourceRank()).view(np.uint32), np.arange(num_backends))
+    # "%s" alone
+    sent = PacketWave(codec, W.USER_STRM_BASE_ID, PROT_BASIC, "%s", [string_col("Test String", num_backends)])
+    got = received(codec, sent)
+    counts, body = got.values(0)
+    assert counts.tolist() == [12] * num_backends and body.tobytes() == b"Test String\0" * num_backends
+
+
+def test_basic_alltypes_packet(codec, golden):
+    g = golden["basic_test"]
+    n = 8
+    cols = []
+    for tok, val in zip([t[1:] for t in g["fmt"].split()], g["values"]):
+        if tok == "s":
+            cols.append(string_col(val, n))
+        else:
+            cols.append(np.full(n, ord(val) if isinstance(val, str) else val, TOK_DTYPE[tok]))
+    sent = PacketWave(codec, W.USER_STRM_BASE_ID, PROT_BASIC, g["fmt"], cols)
+    got = received(codec, sent)
+    assert got.unpack(g["fmt"]) != -1 and not got.has_Error()
+    for i in range(10):
+        assert np.array_equal(got.values(i), cols[i])
+    # compare_Float(f1, f2, 3 digits) of the reference is implied: the values are bit-identical
+    counts, body = got.values(10)
+    assert body.tobytes() == b"Test String\0" * n
+
+
+def test_arrays_round_trip(codec, golden):
+    """tests/test_arrays_FE.C: 5,000 elements of every array type; memcmp(sent, received)."""
+    a = golden["arrays_test"]
+    m, n = a["array_len"], 3
+    for tok, val in a["values"].items():
+        dt = TOK_DTYPE[tok[1:]]
+        body = np.full(n * m, val, dt)
+        sent = PacketWave(codec, W.USER_STRM_BASE_ID, PROT_BASIC, "%" + tok, [(np.full(n, m, np.uint64), body)])
+        got = received(codec, sent)
+        counts, recv = got.values(0)
+        assert counts.tolist() == [m] * n and recv.tobytes() == body.tobytes(), tok
+
+
+@pytest.mark.parametrize("num_backends", [1, 4, 16, 64])
+def test_native_filters_sum(codec, golden, num_backends):
+    """tests/test_NativeFilters_FE.C:122-262 with TFILTER_SUM + SFILTER_WAITFORALL."""
+    g = golden["native_filters_test"]
+    for tok, val in g["values"].items():
+        dt = np.dtype(TOK_DTYPE[tok])
+        wave = PacketWave(codec, W.USER_STRM_BASE_ID, W.FIRST_APPLICATION_TAG + 2, "%" + tok,
+                          [np.full(num_backends, val, dt)])
+        out = tfilter_Sum(received(codec, wave), shape=W.SHAPE_FLAT)
+        assert out.get_StreamId() == W.USER_STRM_BASE_ID and out.get_Tag() == W.FIRST_APPLICATION_TAG + 2
+        assert out.get_FormatString() == "%" + tok and out.size() == 1
+        comp = np.zeros(1, dt)
+        with np.errstate(over="ignore"):
+            for _ in range(num_backends):
+                comp[0] = comp[0] + dt.type(val)
+        assert out.unpack("%" + tok) != -1
+        assert out.values(0)[0].tobytes() == comp[0].tobytes(), (tok, num_backends)
+
+
+def test_filters_min_max_avg_and_rejections(codec):
+    v = np.array([123.45, 1e8, -1e8, 0.1, 3.0], np.float32)
+    wave = PacketWave(codec, 7, 100, "%f", [v])
+    assert tfilter_Max(wave, W.SHAPE_FLAT).values(0)[0] == np.float32(1e8)
+    assert tfilter_Min(wave, W.SHAPE_FLAT).values(0)[0] == np.float32(-1e8)
+    assert "%f" % tfilter_Sum(wave, W.SHAPE_FLAT).values(0)[0] == "123.099998"
+    avg = tfilter_Avg(PacketWave(codec, 7, 100, "%d %d", [np.array([7, 8, 10], np.int32),
+                                                          np.array([1, 2, 4], np.int32)]), W.SHAPE_FLAT)
+    assert avg.get_FormatString() == "%d %d"
+    assert (int(avg.values(0)[0]), int(avg.values(1)[0])) == (9, 7)
+    # formats the built-in filters do not accept produce no output packet
+    assert tfilter_Sum(PacketWave(codec, 7, 100, "%d %d", [np.zeros(2, np.int32), np.zeros(2, np.int32)])) is None
+    assert tfilter_Avg(PacketWave(codec, 7, 100, "%d", [np.zeros(2, np.int32)])) is None
+    assert tfilter_Avg(PacketWave(codec, 7, 100, "%d %d", [np.ones(2, np.int32), np.zeros(2, np.int32)])) is None
+
+
+def test_receive_side_errors(codec):
+    fmt = "%d %ad"
+    n = 50
+    sent = PacketWave(codec, 9, 101, fmt, [np.arange(n, dtype=np.int32),
+                                           (np.full(n, 3, np.uint64), np.arange(3 * n, dtype=np.int32))])
+    # a truncated buffer: ERR_PACKING for that packet, the others decode
+    lens = sent.get_Buffer().lens.clone()
+    lens[10] = 9
+    wire = W.WireWave(sent.get_Buffer().arena, n, sent.get_Buffer().offsets, lens, 0)
+    got = PacketWave.from_buffers(codec, fmt, n, sent.get_Header(), sent.get_HeaderLen(), wire)
+    assert got.unpack(fmt) != -1 and got.has_Error()
+    ok = W.Codec.to_numpy(got.ok)
+    assert ok[10] == 0 and ok.sum() == n - 1
+    # headers that announce another format are refused
+    other = PacketWave(codec, 9, 101, "%d %ald", [np.arange(n, dtype=np.int32),
+                                                  (np.zeros(n, np.uint64), np.zeros(0, np.int64))])
+    bad = PacketWave.from_buffers(codec, fmt, n, other.get_Header(), other.get_HeaderLen(), sent.get_Buffer())
+    assert bad.has_Error()
