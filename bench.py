@@ -226,7 +226,11 @@ def mixed_wave_extra(codec):
     def dec():
         codec.decode_into(fmt, wire, dcols, ok)
     t_enc, t_dec = time_call(enc, 50), time_call(dec, 50)
-    assert bool(ok.all()) and torch.equal(dcols[4].values, cols[4].values) and torch.equal(dcols[3].values, cols[3].values)
+    assert bool(ok.all()) and codec.status() == 0
+    for i in (3, 4):
+        assert torch.equal(dcols[i].values.view(torch.uint8), cols[i].values.view(torch.uint8))
+    for i in (0, 1, 2):
+        assert torch.equal(dcols[i].values.view(torch.uint8), cols[i].values.view(torch.uint8))
     data = int(lens.sum().item())
     decoded = 20 * n + int(slen.sum()) + int(alen.sum())
     nbytes = 2 * (data + decoded) + 8 * (n + 1)

@@ -24,6 +24,7 @@
 #define COPY_UNROLL 4
 #define COPY_PIECE 16u
 #define COPY_CHUNK (MRPDR_TPB * COPY_PIECE * COPY_UNROLL)     // 16 KiB of dense bytes
+#define COPY_LDS_SEGS 1024                                    // packets per chunk staged in LDS
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -84,6 +85,7 @@ struct CopyArgs {
 // One 16 KiB chunk of the dense side.
 struct ChunkDesc {
     uint64_t wire_off;     // arena offset of the wire byte that matches the chunk's first byte
+                           // (chunks that span packets: index of the last packet they touch)
     uint32_t seg;          // packet the chunk starts in
     uint32_t info;         // bytes in the chunk (<= COPY_CHUNK) << 3 | DESC_* flags
 };
@@ -159,6 +161,8 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt,
         d.seg = (uint32_t)sg.s;
         uint32_t flags = ce <= sg.hi ? DESC_SINGLE : 0u;
         const uint32_t delta = (uint32_t)(0 - (uintptr_t)(a.wire.base + d.wire_off)) & 15u;
+        // a chunk that spans packets has no single wire address: the slot carries its last packet
+        if (!flags) d.wire_off = seg_find(a.seg_offs, sg.s, a.n - 1, (ce - 1) / w);
         if (!ENCODE || delta == 0) {
             flags |= DESC_EXTEND;
         } else if (flags && ce - cb == COPY_CHUNK) {
@@ -274,9 +278,70 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, Fmt
         return;
     }
 
-    // chunk spans several packets: every lane locates its own piece
+    // chunk spans several packets.  The workgroup first loads the boundaries and wire addresses
+    // of all packets that touch the chunk into LDS (one packet per lane, in parallel); every
+    // lane then locates its own 16-byte piece with a binary search in LDS.
     const uint64_t ce = cb + len;
-    const uint64_t s_last = seg_find(a.seg_offs, seg, a.n - 1, (ce - 1) / W);
+    const uint64_t s_last = raw.x;
+    const uint64_t nseg = s_last - seg + 1;
+    __shared__ uint64_t s_lo[COPY_LDS_SEGS + 1];
+    __shared__ uint8_t *s_wire[COPY_LDS_SEGS];
+    if (nseg <= COPY_LDS_SEGS) {
+        for (uint32_t i = threadIdx.x; i < nseg; i += MRPDR_TPB) {
+            Seg t;
+            seg_load(t, seg + i, W, a, fmt, cols);
+            s_lo[i] = t.lo;
+            s_wire[i] = t.wire;
+            if (i + 1 == nseg) s_lo[nseg] = t.hi;
+        }
+        __syncthreads();
+        // locate the four pieces and issue their loads together, then store
+        uint32_t at[COPY_UNROLL];
+        bool whole[COPY_UNROLL];
+        u32x4 v[COPY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < COPY_UNROLL; u++) {
+            const uint64_t b = cb + ((uint64_t)u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
+            whole[u] = false;
+            at[u] = 0;
+            if (b >= ce) continue;
+            uint32_t lo = 0, hi = (uint32_t)nseg - 1;          // first i with s_lo[i+1] > b
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_lo[mid + 1] > b) hi = mid; else lo = mid + 1;
+            }
+            at[u] = lo;
+            whole[u] = b + COPY_PIECE <= ce && b + COPY_PIECE <= s_lo[lo + 1];
+            if (whole[u]) v[u] = ENCODE ? ld16<false>(a.dense + b) : ld16_any<false>(s_wire[lo] + (b - s_lo[lo]));
+        }
+#pragma unroll
+        for (int u = 0; u < COPY_UNROLL; u++) {
+            const uint64_t b = cb + ((uint64_t)u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
+            if (b >= ce) continue;
+            uint32_t lo = at[u];
+            if (whole[u]) {
+                if (ENCODE) st16_any<false>(s_wire[lo] + (b - s_lo[lo]), v[u]);
+                else        st16<false>(a.dense + b, SWAP ? swap_elems<W>(v[u]) : v[u]);
+            } else {
+                const uint64_t e = (b + COPY_PIECE < ce) ? b + COPY_PIECE : ce;
+                for (uint64_t p = b; p < e; p += W) {
+                    while (p >= s_lo[lo + 1]) lo++;             // next packet (skips empty arrays)
+                    uint8_t *wp = s_wire[lo] + (p - s_lo[lo]);
+                    if (ENCODE) {
+                        st_u<U>(wp, ld_u<U>(a.dense + p));
+                    } else {
+                        U x = ld_u<U>(wp);
+                        if (SWAP) x = bswap_u(x);
+                        st_u<U>(a.dense + p, x);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // more packets in one chunk than the LDS table holds (arrays of a few bytes): every lane
+    // searches the offsets in global memory
 #pragma unroll 1
     for (int u = 0; u < COPY_UNROLL; u++) {
         const uint64_t b = cb + ((uint64_t)u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
@@ -293,6 +358,58 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, Fmt
             }
         } else {
             copy_elems<W, SWAP, ENCODE>(t, b, e, a, fmt, cols);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Short payloads: packet-centric copy
+// ---------------------------------------------------------------------------
+// When the packets of a wave carry short arrays or strings (tens to hundreds of bytes) a
+// 16 KiB chunk holds dozens to thousands of them and the column is only a few hundred
+// chunks long: the chunk kernel above is short of parallelism and spends its time finding
+// packet boundaries.  Here 16 lanes take one packet: 128-bit pieces while they fit, then
+// the last few elements one per lane.  n/16 wavefront quarters in flight instead of
+// bytes/16Ki workgroups.
+#define PKT_LANES 16u
+
+template <int W, bool SWAP, bool ENCODE>
+__global__ __launch_bounds__(MRPDR_TPB) void k_copy_packets(CopyArgs a, FmtDev fmt, ColsDev cols)
+{
+    typedef typename UIntOf<W>::type U;
+    const uint64_t s = ((uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x) / PKT_LANES;
+    const uint32_t lane = threadIdx.x % PKT_LANES;
+    if (a.seg_offs[a.n] * W > a.dense_cap) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(a.status, 1u);
+        return;
+    }
+    if (s >= a.n) return;
+    Seg sg;
+    seg_load(sg, s, W, a, fmt, cols);
+    const uint64_t len = sg.hi - sg.lo;
+    uint8_t *dense = a.dense + sg.lo;
+    for (uint64_t base = 0; base < len; base += PKT_LANES * COPY_PIECE) {
+        const uint64_t rem = len - base;
+        const uint32_t full = rem >= PKT_LANES * COPY_PIECE ? PKT_LANES : (uint32_t)(rem / COPY_PIECE);
+        if (lane < full) {
+            const uint64_t b = base + lane * COPY_PIECE;
+            if (ENCODE) st16_any<false>(sg.wire + b, ld16_any<false>(dense + b));
+            else {
+                u32x4 x = ld16_any<false>(sg.wire + b);
+                st16_any<false>(dense + b, SWAP ? swap_elems<W>(x) : x);
+            }
+        } else {
+            // the lanes without a whole piece share the last (< 16 byte) run, one element each
+            const uint64_t t0 = base + (uint64_t)full * COPY_PIECE;
+            for (uint64_t e = t0 + (uint64_t)(lane - full) * W; e < len; e += (uint64_t)(PKT_LANES - full) * W) {
+                if (ENCODE) {
+                    st_u<U>(sg.wire + e, ld_u<U>(dense + e));
+                } else {
+                    U x = ld_u<U>(sg.wire + e);
+                    if (SWAP) x = bswap_u(x);
+                    st_u<U>(dense + e, x);
+                }
+            }
         }
     }
 }

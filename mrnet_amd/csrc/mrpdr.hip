@@ -414,6 +414,19 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
 {
     // upper bound of the payload: it cannot exceed the arena or the column
     const uint64_t bound = a.wire.bytes < a.dense_cap ? a.wire.bytes : a.dense_cap;
+    // short payloads (under 2 KiB per packet on average): 16 lanes per packet
+    if (bound / a.n < 2048) {
+        const uint64_t threads = a.n * PKT_LANES;
+        const bool timed = c->perf_on && c->perf_used < PERF_SLOTS;
+        if (timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
+        k_copy_packets<W, SWAP, ENCODE><<<blocks_for(threads, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd);
+        LAUNCHED("k_copy_packets");
+        if (timed) {
+            HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used + 1], st));
+            c->perf_kind[c->perf_used++] = ENCODE ? 1 : 0;
+        }
+        return 1;
+    }
     const uint64_t chunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
     // data this large is touched once per kernel: keep it out of the caches
     const bool nt = bound >= (32ull << 20);

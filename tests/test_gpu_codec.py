@@ -330,3 +330,22 @@ def test_full_size_array_wave_properties(codec):
     cols2, ok2 = codec.decode(fmt, le, W.LITTLEENDIAN)
     assert bool(ok2.all()) and torch.equal(cols2[0].values, cols[0].values)
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("fmt_s,n,giant_every,giant,small", [("%auc", 3000, 100, 1000000, 40),
+                                                             ("%ad", 30000, 10000, 7000000, 1),
+                                                             ("%hd %s %ahd", 2000, 500, 3000000, 9)])
+def test_skewed_segment_sizes(codec, fmt_s, n, giant_every, giant, small):
+    """A few huge arrays among many tiny ones: the chunked payload kernel meets chunks holding
+    one packet, dozens of packets (boundaries staged in LDS) and thousands of packets."""
+    fmt = W.Format(fmt_s)
+    f = len(fmt) - 1
+    cnt = (np.arange(n, dtype=np.uint64) * np.uint64(2654435761) >> np.uint64(7)) % np.uint64(small + 1)
+    cnt[giant_every // 2::giant_every] = giant
+    ocols = make_wave(fmt_s, n, seed=n, max_count=5, counts={f: cnt})
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    wire = codec.encode(fmt, dev_cols(codec, fmt, ocols), n)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    be = to_sender_order(fmt_s, arena, offs, lens)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, be, offs, lens), W.BIGENDIAN)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
