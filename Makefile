@@ -5,7 +5,9 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -fPIC -shared -fwrapv -ffp-contract=off -s
 SRC      = mrnet_amd/csrc
 LIB      = mrnet_amd/lib/libmrpdr.so
 
-all: $(LIB) oracle
+HOSTTEST = tests/host/test_packet_wave
+
+all: $(LIB) oracle $(HOSTTEST)
 
 $(LIB): $(SRC)/mrpdr.hip $(SRC)/common.h $(SRC)/scan.h $(SRC)/rows.h $(SRC)/copy.h $(SRC)/filter.h $(SRC)/header.h include/mrpdr.h
 	mkdir -p mrnet_amd/lib
@@ -14,8 +16,13 @@ $(LIB): $(SRC)/mrpdr.hip $(SRC)/common.h $(SRC)/scan.h $(SRC)/rows.h $(SRC)/copy
 oracle:
 	$(MAKE) -C oracle
 
+# C++ host layer (mrnet_amd/host/PacketWave.h) exercised by a reference-style test program
+$(HOSTTEST): tests/host/test_packet_wave.cpp mrnet_amd/host/PacketWave.h include/mrpdr.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Wall -o $@ tests/host/test_packet_wave.cpp -Lmrnet_amd/lib -lmrpdr \
+		-Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib'
+
 clean:
-	rm -f $(LIB)
+	rm -f $(LIB) $(HOSTTEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

@@ -1,0 +1,373 @@
+// C++ host side of the wave codec: the reference's Packet surface for n packets at a time,
+// over the C ABI of include/mrpdr.h.  Host buffers in, host buffers out -- the legacy
+// boundary of src/Packet.C (malloc'ed hdr/buf blocks, caller-owned unpacked arrays); the HIP
+// kernels do all encoding, decoding and filtering.  Header-only; link -lmrpdr -lamdhip64.
+//
+// Mirrors include/mrnet/Packet.h:41-118:
+//   PacketWave(ctx, stream_id, tag, fmt, cols, n)   API constructor, encodes the data at once
+//                                                    (src/Packet.C:137-165 -> encode_pdr_data)
+//   PacketWave(ctx, fmt, n, hdrs, hdr_len, bufs..)  receive-side constructor: headers decoded at
+//                                                    once, data lazily (src/Packet.C:277-295)
+//   unpack(fmt, cols)                               -1 when fmt differs (src/Packet.C:527-532)
+//   get_Header / get_Buffer                         encoded bytes (header encoded lazily,
+//                                                    src/Message.C:288-292)
+//   tfilter_Sum / Max / Min / Avg                   one output packet with the stream id and tag
+//                                                    of the first input (src/FilterDefinitions.C:151-221)
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mrpdr.h"
+
+namespace MRN_GPU {
+
+struct PdrError : std::runtime_error {
+    explicit PdrError(const std::string &what) : std::runtime_error(what + ": " + mrpdr_last_error()) {}
+};
+
+inline void hip_check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+// One field of a wave in host memory.  Scalars: values holds n elements.  Arrays and strings:
+// counts[i] elements in packet i (a string counts strlen+1), values holds them back to back.
+struct HostColumn {
+    std::vector<uint8_t>  values;
+    std::vector<uint64_t> counts;
+    template <typename T> void set_scalars(const std::vector<T> &v)
+    {
+        values.assign((const uint8_t *)v.data(), (const uint8_t *)(v.data() + v.size()));
+        counts.clear();
+    }
+    template <typename T> void set_arrays(const std::vector<uint64_t> &cnt, const std::vector<T> &v)
+    {
+        values.assign((const uint8_t *)v.data(), (const uint8_t *)(v.data() + v.size()));
+        counts = cnt;
+    }
+    template <typename T> const T *as() const { return (const T *)values.data(); }
+};
+
+class DeviceBuffer {
+ public:
+    DeviceBuffer() : p_(nullptr), bytes_(0) {}
+    ~DeviceBuffer() { if (p_) (void)hipFree(p_); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    void resize(size_t bytes)
+    {
+        if (bytes <= bytes_ && p_) return;
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr;
+        bytes_ = bytes ? bytes : 16;
+        hip_check(hipMalloc(&p_, bytes_), "hipMalloc");
+    }
+    void upload(const void *src, size_t bytes, hipStream_t s)
+    {
+        resize(bytes);
+        if (bytes) hip_check(hipMemcpyAsync(p_, src, bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync H2D");
+    }
+    void download(void *dst, size_t bytes, hipStream_t s) const
+    {
+        if (bytes) hip_check(hipMemcpyAsync(dst, p_, bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync D2H");
+    }
+    template <typename T> T *ptr() const { return (T *)p_; }
+    size_t bytes() const { return bytes_; }
+ private:
+    void *p_;
+    size_t bytes_;
+};
+
+// One per calling thread: device context + stream (the reference runs one filter at a time
+// per Filter object, src/Filter.C:76-83, but different streams on different threads).
+class WaveContext {
+ public:
+    explicit WaveContext(int device = 0, uint64_t max_packets = 1 << 21)
+    {
+        hip_check(hipSetDevice(device), "hipSetDevice");
+        hip_check(hipStreamCreate(&stream), "hipStreamCreate");
+        ctx = mrpdr_ctx_create(device, max_packets);
+        if (!ctx) throw PdrError("mrpdr_ctx_create");
+    }
+    ~WaveContext()
+    {
+        mrpdr_ctx_destroy(ctx);
+        (void)hipStreamDestroy(stream);
+    }
+    void sync() { hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    mrpdr_ctx *ctx;
+    hipStream_t stream;
+};
+
+class PacketWave {
+ public:
+    // ---- API constructor: values -> encoded packets ----------------------------------
+    PacketWave(WaveContext &wc, uint32_t stream_id, int32_t tag, const char *fmt,
+               const std::vector<HostColumn> &cols, uint64_t n)
+        : wc_(wc), fmt_(mrpdr_fmt_compile(fmt)), n_(n), stream_id_(stream_id), tag_(tag),
+          byteorder_(MRPDR_LITTLEENDIAN), decoded_(true), error_(false), have_hdrs_(false)
+    {
+        if (!fmt_) throw PdrError("mrpdr_fmt_compile");
+        upload_columns(cols);
+        encode_pdr_data();
+    }
+
+    // ---- receive-side constructor: encoded packets as Message::recv leaves them --------
+    // hdrs: n headers of hdr_len bytes each, back to back.  bufs: the data buffers in one
+    // block, packet i at buf_offsets[i], buf_lens[i] long.
+    PacketWave(WaveContext &wc, const char *fmt, uint64_t n, const char *hdrs, unsigned hdr_len,
+               const char *bufs, const uint64_t *buf_offsets, const uint64_t *buf_lens, uint64_t buf_bytes)
+        : wc_(wc), fmt_(mrpdr_fmt_compile(fmt)), n_(n), stream_id_((uint32_t)-1), tag_(-1),
+          byteorder_(MRPDR_LITTLEENDIAN), decoded_(false), error_(false), have_hdrs_(true)
+    {
+        if (!fmt_) throw PdrError("mrpdr_fmt_compile");
+        hdr_len_ = hdr_len;
+        d_hdrs_.upload(hdrs, (size_t)n * hdr_len, wc_.stream);
+        d_arena_.upload(bufs, buf_bytes, wc_.stream);
+        d_offs_.upload(buf_offsets, 8 * n, wc_.stream);
+        d_lens_.upload(buf_lens, 8 * n, wc_.stream);
+        arena_bytes_ = buf_bytes;
+        decode_pdr_header();
+    }
+
+    ~PacketWave() { mrpdr_fmt_free(fmt_); }
+    PacketWave(const PacketWave &) = delete;
+    PacketWave &operator=(const PacketWave &) = delete;
+
+    // ---- accessors ---------------------------------------------------------------------
+    int32_t get_Tag() const { return tag_; }
+    uint32_t get_StreamId() const { return stream_id_; }
+    const char *get_FormatString() const { return mrpdr_fmt_string(fmt_); }
+    uint64_t size() const { return n_; }
+    bool has_Error() const { return error_; }
+    const std::vector<uint32_t> &get_SourceRanks() const { return src_ranks_; }
+    const std::vector<int32_t> &ok() const { return ok_; }
+
+    // Encoded data buffers in host memory: packet i at offsets[i], lens[i] long.
+    void get_Buffers(std::vector<uint8_t> &arena, std::vector<uint64_t> &offsets, std::vector<uint64_t> &lens)
+    {
+        arena.resize(arena_bytes_);
+        offsets.resize(n_);
+        lens.resize(n_);
+        d_arena_.download(arena.data(), arena_bytes_, wc_.stream);
+        d_offs_.download(offsets.data(), 8 * n_, wc_.stream);
+        d_lens_.download(lens.data(), 8 * n_, wc_.stream);
+        wc_.sync();
+    }
+    unsigned get_HeaderLen() const { return (unsigned)mrpdr_header_bytes(fmt_); }
+    // Encoded headers, get_HeaderLen() bytes each (lazy: Message::send asks for them).
+    void get_Headers(std::vector<uint8_t> &hdrs, const std::vector<uint32_t> *src_ranks = nullptr)
+    {
+        if (!have_hdrs_) encode_pdr_header(src_ranks);
+        hdrs.resize((size_t)n_ * hdr_len_);
+        d_hdrs_.download(hdrs.data(), hdrs.size(), wc_.stream);
+        wc_.sync();
+    }
+
+    // Packet::unpack: -1 when the format differs, else the decoded fields in host memory
+    // (caller-owned copies, as DataElementArray2ArgList hands out, src/Packet.C:1065-1431).
+    int unpack(const char *fmt, std::vector<HostColumn> &out)
+    {
+        decode_pdr_data();
+        if (!fmt || strcmp(fmt, get_FormatString()) != 0) return -1;
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        out.assign(nf, HostColumn());
+        for (int f = 0; f < nf; f++) {
+            const int w = mrpdr_fmt_field_width(fmt_, f);
+            if (mrpdr_fmt_field_kind(fmt_, f) == MRPDR_SCALAR) {
+                out[f].values.resize(n_ * w);
+                d_values_[f].download(out[f].values.data(), n_ * w, wc_.stream);
+            } else {
+                out[f].counts.resize(n_);
+                d_counts_[f].download(out[f].counts.data(), 8 * n_, wc_.stream);
+                out[f].values.resize(totals_[f] * w);
+                d_values_[f].download(out[f].values.data(), totals_[f] * w, wc_.stream);
+            }
+        }
+        wc_.sync();
+        return 0;
+    }
+
+    // device views for the filters
+    const mrpdr_wire &wire() const { return wire_; }
+    const mrpdr_fmt *format() const { return fmt_; }
+    int32_t byteorder() const { return byteorder_; }
+    const std::vector<mrpdr_column> &columns() { decode_pdr_data(); return cols_; }
+    WaveContext &context() const { return wc_; }
+
+ private:
+    void alloc_column_structs()
+    {
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        d_values_ = std::vector<DeviceBuffer>(nf);
+        d_counts_ = std::vector<DeviceBuffer>(nf);
+        d_coffs_ = std::vector<DeviceBuffer>(nf);
+        cols_.assign(nf, mrpdr_column());
+        totals_.assign(nf, 0);
+    }
+
+    void upload_columns(const std::vector<HostColumn> &cols)
+    {
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        if ((int)cols.size() != nf) throw std::runtime_error("PacketWave: one column per format token");
+        alloc_column_structs();
+        for (int f = 0; f < nf; f++) {
+            const int w = mrpdr_fmt_field_width(fmt_, f);
+            d_values_[f].upload(cols[f].values.data(), cols[f].values.size(), wc_.stream);
+            cols_[f].values = d_values_[f].ptr<void>();
+            cols_[f].capacity = cols[f].values.size() / w;
+            if (mrpdr_fmt_field_kind(fmt_, f) != MRPDR_SCALAR) {
+                std::vector<uint64_t> offs(n_ + 1, 0);
+                for (uint64_t i = 0; i < n_; i++) offs[i + 1] = offs[i] + cols[f].counts[i];
+                totals_[f] = offs[n_];
+                d_counts_[f].upload(cols[f].counts.data(), 8 * n_, wc_.stream);
+                d_coffs_[f].upload(offs.data(), 8 * (n_ + 1), wc_.stream);
+                wc_.sync();     // offs is a local
+                cols_[f].counts = d_counts_[f].ptr<uint64_t>();
+                cols_[f].offs = d_coffs_[f].ptr<uint64_t>();
+            }
+        }
+    }
+
+    void encode_pdr_data()                       // src/Packet.C:54-85, for the whole wave
+    {
+        d_offs_.resize(8 * (n_ + 1));
+        d_lens_.resize(8 * n_);
+        uint64_t total = 0;
+        if (!mrpdr_wave_sizeof(wc_.ctx, fmt_, cols_.data(), n_, 16, 0, d_lens_.ptr<uint64_t>(),
+                               d_offs_.ptr<uint64_t>(), &total, wc_.stream)) throw PdrError("mrpdr_wave_sizeof");
+        arena_bytes_ = total;
+        d_arena_.resize(total);
+        hip_check(hipMemsetAsync(d_arena_.ptr<void>(), 0, d_arena_.bytes(), wc_.stream), "hipMemsetAsync");
+        wire_ = mrpdr_wire{ d_arena_.ptr<uint8_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, total };
+        if (!mrpdr_wave_encode(wc_.ctx, fmt_, cols_.data(), n_, &wire_, wc_.stream)) throw PdrError("mrpdr_wave_encode");
+    }
+
+    void encode_pdr_header(const std::vector<uint32_t> *src_ranks)      // src/Packet.C:20-52
+    {
+        hdr_len_ = get_HeaderLen();
+        d_hdrs_.resize((size_t)n_ * hdr_len_);
+        DeviceBuffer d_src;
+        const uint32_t *src = nullptr;
+        if (src_ranks) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
+        if (!mrpdr_wave_encode_headers(wc_.ctx, fmt_, n_, stream_id_, nullptr, tag_, nullptr, 0xFFFFFFFFu, src,
+                                       d_hdrs_.ptr<uint8_t>(), hdr_len_, wc_.stream)) throw PdrError("mrpdr_wave_encode_headers");
+        wc_.sync();
+        have_hdrs_ = true;
+    }
+
+    void decode_pdr_header()                     // src/Packet.C:87-104
+    {
+        DeviceBuffer d_sid, d_tag, d_src, d_bo, d_ok;
+        d_sid.resize(4 * n_); d_tag.resize(4 * n_); d_src.resize(4 * n_); d_bo.resize(n_); d_ok.resize(4 * n_);
+        if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, d_hdrs_.ptr<uint8_t>(), nullptr, nullptr, hdr_len_,
+                                       d_sid.ptr<uint32_t>(), d_tag.ptr<int32_t>(), d_src.ptr<uint32_t>(),
+                                       d_bo.ptr<uint8_t>(), nullptr, d_ok.ptr<int32_t>(), wc_.stream))
+            throw PdrError("mrpdr_wave_decode_headers");
+        std::vector<uint32_t> sid(n_);
+        std::vector<int32_t> tag(n_), okh(n_);
+        std::vector<uint8_t> bo(n_);
+        src_ranks_.resize(n_);
+        d_sid.download(sid.data(), 4 * n_, wc_.stream); d_tag.download(tag.data(), 4 * n_, wc_.stream);
+        d_src.download(src_ranks_.data(), 4 * n_, wc_.stream); d_bo.download(bo.data(), n_, wc_.stream);
+        d_ok.download(okh.data(), 4 * n_, wc_.stream);
+        wc_.sync();
+        if (n_) { stream_id_ = sid[0]; tag_ = tag[0]; byteorder_ = bo[0]; }
+        for (uint64_t i = 0; i < n_; i++)
+            if (!okh[i] || bo[i] != bo[0]) error_ = true;     // foreign format or mixed byte orders
+        wire_ = mrpdr_wire{ d_arena_.ptr<uint8_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, arena_bytes_ };
+    }
+
+    void decode_pdr_data()                       // src/Packet.C:106-133, lazy and idempotent
+    {
+        if (decoded_) return;
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        alloc_column_structs();
+        for (int f = 0; f < nf; f++) {
+            const int w = mrpdr_fmt_field_width(fmt_, f);
+            if (mrpdr_fmt_field_kind(fmt_, f) == MRPDR_SCALAR) {
+                d_values_[f].resize(n_ * w);
+                cols_[f].values = d_values_[f].ptr<void>();
+                cols_[f].capacity = n_;
+            } else {
+                d_counts_[f].resize(8 * n_);
+                d_coffs_[f].resize(8 * (n_ + 1));
+                cols_[f].counts = d_counts_[f].ptr<uint64_t>();
+                cols_[f].offs = d_coffs_[f].ptr<uint64_t>();
+            }
+        }
+        DeviceBuffer d_ok;
+        d_ok.resize(4 * n_);
+        if (!mrpdr_wave_decode_begin(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), d_ok.ptr<int32_t>(),
+                                     totals_.data(), wc_.stream)) throw PdrError("mrpdr_wave_decode_begin");
+        for (int f = 0; f < nf; f++)
+            if (mrpdr_fmt_field_kind(fmt_, f) != MRPDR_SCALAR) {
+                d_values_[f].resize(totals_[f] * mrpdr_fmt_field_width(fmt_, f));
+                cols_[f].values = d_values_[f].ptr<void>();
+                cols_[f].capacity = totals_[f];
+            }
+        if (!mrpdr_wave_decode_finish(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), wc_.stream))
+            throw PdrError("mrpdr_wave_decode_finish");
+        ok_.resize(n_);
+        d_ok.download(ok_.data(), 4 * n_, wc_.stream);
+        wc_.sync();
+        for (uint64_t i = 0; i < n_; i++)
+            if (!ok_[i]) error_ = true;          // error(ERR_PACKING, ...), src/Packet.C:122-124
+        decoded_ = true;
+    }
+
+    WaveContext &wc_;
+    mrpdr_fmt *fmt_;
+    uint64_t n_;
+    uint32_t stream_id_;
+    int32_t tag_;
+    int32_t byteorder_;
+    bool decoded_, error_, have_hdrs_;
+    unsigned hdr_len_ = 0;
+    uint64_t arena_bytes_ = 0;
+    DeviceBuffer d_hdrs_, d_arena_, d_offs_, d_lens_;
+    std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_;
+    std::vector<mrpdr_column> cols_;
+    std::vector<uint64_t> totals_;
+    std::vector<uint32_t> src_ranks_;
+    std::vector<int32_t> ok_;
+    mrpdr_wire wire_{};
+};
+
+// ---- built-in transformation filters over a wave ------------------------------------------
+// Returns 0 and the data bytes of the output packet (T value[, int32 count]) in result16, or -1
+// when the filter emits nothing (format it does not accept, empty wave, zero count sum).
+inline int run_tfilter(int op, PacketWave &in, int shape, uint8_t result16[16], std::string *out_fmt)
+{
+    const mrpdr_fmt *f = in.format();
+    const int nf = mrpdr_fmt_nfields(f);
+    const int want = op == MRPDR_AVG ? 2 : 1;
+    if (in.size() == 0 || in.has_Error() || nf != want || mrpdr_fmt_field_kind(f, 0) != MRPDR_SCALAR) return -1;
+    if (op == MRPDR_AVG && mrpdr_fmt_field_type(f, 1) != MRPDR_INT32_T) return -1;
+    const std::vector<mrpdr_column> &cols = in.columns();
+    WaveContext &wc = in.context();
+    DeviceBuffer d_res, d_ok;
+    d_res.resize(16); d_ok.resize(4);
+    const int w = mrpdr_fmt_field_width(f, 0);
+    if (!mrpdr_wave_filter(wc.ctx, op, mrpdr_fmt_field_type(f, 0), shape, cols[0].values, (uint64_t)w,
+                           op == MRPDR_AVG ? cols[1].values : nullptr, 4, in.size(), 0,
+                           d_res.ptr<void>(), d_ok.ptr<int32_t>(), wc.stream)) throw PdrError("mrpdr_wave_filter");
+    int32_t ok = 0;
+    d_res.download(result16, 16, wc.stream);
+    d_ok.download(&ok, 4, wc.stream);
+    wc.sync();
+    if (out_fmt) *out_fmt = in.get_FormatString();
+    return ok ? 0 : -1;
+}
+inline int tfilter_Sum(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_SUM, in, shape, r, nullptr); }
+inline int tfilter_Max(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MAX, in, shape, r, nullptr); }
+inline int tfilter_Min(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MIN, in, shape, r, nullptr); }
+inline int tfilter_Avg(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_AVG, in, shape, r, nullptr); }
+
+} // namespace MRN_GPU

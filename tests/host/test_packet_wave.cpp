@@ -1,0 +1,219 @@
+// C++ host-side test of mrnet_amd/host/PacketWave.h, in the style of the reference's
+// test harness (tests/test_common.C:41-187): every sub-test prints MRNTEST_SUCCESS or
+// MRNTEST_FAILURE, and the driver greps the output for "failure" (tests/mrnet_tests.sh:119-130).
+//
+// Sub-tests follow tests/test_basic_FE.C (alltypes packet), tests/test_arrays_FE.C
+// (ARRAY_LEN elements, memcmp) and tests/test_NativeFilters_FE.C (TFILTER_SUM over a
+// constant per back-end), plus the byte vectors captured from the compiled reference.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../mrnet_amd/host/PacketWave.h"
+
+using namespace MRN_GPU;
+
+static int failures = 0;
+static void end_SubTest(const std::string &name, bool ok)
+{
+    printf("%s: %s\n", name.c_str(), ok ? "MRNTEST_SUCCESS" : "MRNTEST_FAILURE");
+    if (!ok) failures++;
+}
+
+static std::vector<uint8_t> from_hex(const char *hex)
+{
+    std::vector<uint8_t> out;
+    for (const char *p = hex; *p;) {
+        if (*p == ' ') { p++; continue; }
+        unsigned v;
+        sscanf(p, "%2x", &v);
+        out.push_back((uint8_t)v);
+        p += 2;
+    }
+    return out;
+}
+
+template <typename T> static HostColumn scalars(uint64_t n, T v)
+{
+    HostColumn c;
+    c.set_scalars(std::vector<T>(n, v));
+    return c;
+}
+
+static HostColumn strings(uint64_t n, const char *s)
+{
+    HostColumn c;
+    const size_t l = strlen(s) + 1;
+    for (uint64_t i = 0; i < n; i++) {
+        c.counts.push_back(l);
+        c.values.insert(c.values.end(), (const uint8_t *)s, (const uint8_t *)s + l);
+    }
+    return c;
+}
+
+// What the front-end holds after Message::recv: headers and data buffers of the wave.
+static PacketWave *received(WaveContext &wc, PacketWave &sent)
+{
+    std::vector<uint8_t> hdrs, arena;
+    std::vector<uint64_t> offs, lens;
+    std::vector<uint32_t> src(sent.size());
+    for (uint64_t i = 0; i < sent.size(); i++) src[i] = (uint32_t)i;
+    sent.get_Headers(hdrs, &src);
+    sent.get_Buffers(arena, offs, lens);
+    return new PacketWave(wc, sent.get_FormatString(), sent.size(), (const char *)hdrs.data(),
+                          sent.get_HeaderLen(), (const char *)arena.data(), offs.data(), lens.data(), arena.size());
+}
+
+static void test_golden(WaveContext &wc)
+{
+    // new_Packet_t_2(0x40000010, 101, "%d %uld %lf %s %auc %af", -17, 17, 123.5, "hi", {aa,bb}, {1,2.5,-3})
+    const char *fmt = "%d %uld %lf %s %auc %af";
+    std::vector<HostColumn> cols(6);
+    cols[0] = scalars<int32_t>(1, -17);
+    cols[1] = scalars<uint64_t>(1, 17);
+    cols[2] = scalars<double>(1, 123.5);
+    cols[3] = strings(1, "hi");
+    cols[4].set_arrays(std::vector<uint64_t>{2}, std::vector<uint8_t>{0xAA, 0xBB});
+    cols[5].set_arrays(std::vector<uint64_t>{3}, std::vector<float>{1.0f, 2.5f, -3.0f});
+    PacketWave pkt(wc, 0x40000010u, 101, fmt, cols, 1);
+    std::vector<uint8_t> hdrs, arena;
+    std::vector<uint64_t> offs, lens;
+    pkt.get_Headers(hdrs);
+    pkt.get_Buffers(arena, offs, lens);
+    const std::vector<uint8_t> want_hdr = from_hex(
+        "10 00 00 40 65 00 00 00 ff ff ff ff 18 00 00 00 25 64 20 25 75 6c 64 20 25 6c 66 20 25 73 20 25 61 75 63 "
+        "20 25 61 66 00 00 00 00 00 00 00 00 00 00");
+    const std::vector<uint8_t> want_buf = from_hex(
+        "ef ff ff ff 11 00 00 00 00 00 00 00 00 00 00 00 00 e0 5e 40 03 00 00 00 68 69 00 02 00 00 00 00 00 00 00 "
+        "aa bb 03 00 00 00 00 00 00 00 00 00 80 3f 00 00 20 40 00 00 40 c0");
+    end_SubTest("golden(header bytes)", hdrs == want_hdr);
+    end_SubTest("golden(data bytes)", lens[0] == 57 && std::vector<uint8_t>(arena.begin() + offs[0], arena.begin() + offs[0] + 57) == want_buf);
+}
+
+static void test_alltypes(WaveContext &wc, uint64_t nb)
+{
+    const char *fmt = "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s";
+    std::vector<HostColumn> cols(11);
+    cols[0] = scalars<char>(nb, 'A');        cols[1] = scalars<unsigned char>(nb, 'B');
+    cols[2] = scalars<int16_t>(nb, -17);     cols[3] = scalars<uint16_t>(nb, 17);
+    cols[4] = scalars<int32_t>(nb, -17);     cols[5] = scalars<uint32_t>(nb, 17);
+    cols[6] = scalars<int64_t>(nb, -17);     cols[7] = scalars<uint64_t>(nb, 17);
+    cols[8] = scalars<float>(nb, 123.23412f); cols[9] = scalars<double>(nb, 123.23412);
+    cols[10] = strings(nb, "Test String");
+    PacketWave sent(wc, (1u << 30) + 10, 101, fmt, cols, nb);
+    PacketWave *got = received(wc, sent);
+    std::vector<HostColumn> out;
+    bool ok = !got->has_Error() && got->get_StreamId() == (1u << 30) + 10 && got->get_Tag() == 101;
+    ok = ok && got->unpack("%d", out) == -1;                 // format mismatch
+    ok = ok && got->unpack(fmt, out) == 0;
+    for (int f = 0; ok && f < 11; f++) ok = out[f].values == cols[f].values && out[f].counts == cols[f].counts;
+    for (uint64_t i = 0; ok && i < nb; i++) ok = got->get_SourceRanks()[i] == i;
+    end_SubTest("test_alltypes(" + std::to_string(nb) + " back-ends)", ok);
+    delete got;
+}
+
+template <typename T> static void test_array(WaveContext &wc, const char *fmt, T val)
+{
+    const uint64_t ARRAY_LEN = 5000, nb = 4;
+    std::vector<HostColumn> cols(1);
+    cols[0].set_arrays(std::vector<uint64_t>(nb, ARRAY_LEN), std::vector<T>(nb * ARRAY_LEN, val));
+    PacketWave sent(wc, (1u << 30) + 10, 102, fmt, cols, nb);
+    PacketWave *got = received(wc, sent);
+    std::vector<HostColumn> out;
+    bool ok = got->unpack(fmt, out) == 0 && out[0].counts == cols[0].counts &&
+              out[0].values.size() == cols[0].values.size() &&
+              memcmp(out[0].values.data(), cols[0].values.data(), cols[0].values.size()) == 0;
+    end_SubTest(std::string("test_array(") + fmt + ")", ok);
+    delete got;
+}
+
+template <typename T> static void test_sum(WaveContext &wc, const char *fmt, T val, uint64_t nb)
+{
+    std::vector<HostColumn> cols(1);
+    cols[0] = scalars<T>(nb, val);
+    PacketWave sent(wc, (1u << 30) + 10, 103, fmt, cols, nb);
+    PacketWave *got = received(wc, sent);
+    uint8_t res[16];
+    T comp = 0;
+    for (uint64_t i = 0; i < nb; i++) comp = (T)(comp + val);          // tests/test_NativeFilters_FE.C:122-262
+    bool ok = tfilter_Sum(*got, res, MRPDR_SHAPE_FLAT) == 0 && memcmp(res, &comp, sizeof(T)) == 0;
+    end_SubTest(std::string("test_Sum(") + fmt + ", " + std::to_string(nb) + ")", ok);
+    delete got;
+}
+
+static void test_filters_known_answers(WaveContext &wc)
+{
+    std::vector<HostColumn> cols(1);
+    cols[0].set_scalars(std::vector<float>{123.45f, 1e8f, -1e8f, 0.1f, 3.0f});
+    PacketWave wave(wc, 7, 100, "%f", cols, 5);
+    uint8_t r[16];
+    float f;
+    char txt[64];
+    bool ok = tfilter_Sum(wave, r, MRPDR_SHAPE_FLAT) == 0;
+    memcpy(&f, r, 4); snprintf(txt, sizeof txt, "%f", f);
+    ok = ok && !strcmp(txt, "123.099998");
+    ok = ok && tfilter_Max(wave, r, MRPDR_SHAPE_FLAT) == 0 && (memcpy(&f, r, 4), f == 1e8f);
+    ok = ok && tfilter_Min(wave, r, MRPDR_SHAPE_FLAT) == 0 && (memcpy(&f, r, 4), f == -1e8f);
+    end_SubTest("tfilter_Sum/Max/Min(captured reference results)", ok);
+    std::vector<HostColumn> a(2);
+    a[0].set_scalars(std::vector<int32_t>{7, 8, 10});
+    a[1].set_scalars(std::vector<int32_t>{1, 2, 4});
+    PacketWave avg(wc, 7, 100, "%d %d", a, 3);
+    int32_t v[2];
+    ok = tfilter_Avg(avg, r, MRPDR_SHAPE_FLAT) == 0 && (memcpy(v, r, 8), v[0] == 9 && v[1] == 7);
+    ok = ok && tfilter_Sum(avg, r) == -1;                  // "%d %d" is not a format tfilter_Sum accepts
+    end_SubTest("tfilter_Avg(captured reference result)", ok);
+}
+
+static void test_truncated(WaveContext &wc)
+{
+    const char *fmt = "%d %ad";
+    const uint64_t nb = 40;
+    std::vector<HostColumn> cols(2);
+    cols[0] = scalars<int32_t>(nb, 5);
+    cols[1].set_arrays(std::vector<uint64_t>(nb, 3), std::vector<int32_t>(nb * 3, 9));
+    PacketWave sent(wc, 9, 101, fmt, cols, nb);
+    std::vector<uint8_t> hdrs, arena;
+    std::vector<uint64_t> offs, lens;
+    sent.get_Headers(hdrs);
+    sent.get_Buffers(arena, offs, lens);
+    lens[7] = 9;                                            // cut inside the array count
+    PacketWave got(wc, fmt, nb, (const char *)hdrs.data(), sent.get_HeaderLen(), (const char *)arena.data(),
+                   offs.data(), lens.data(), arena.size());
+    std::vector<HostColumn> out;
+    bool ok = got.unpack(fmt, out) == 0 && got.has_Error();
+    uint64_t good = 0;
+    for (uint64_t i = 0; i < nb; i++) good += got.ok()[i] != 0;
+    ok = ok && good == nb - 1 && got.ok()[7] == 0 && out[1].counts[7] == 0 && out[1].counts[8] == 3;
+    end_SubTest("truncated buffer fails per packet", ok);
+}
+
+int main()
+{
+    try {
+        WaveContext wc(0, 1 << 16);
+        test_golden(wc);
+        for (uint64_t nb : {1, 4, 16}) test_alltypes(wc, nb);
+        test_array<char>(wc, "%ac", -17);            test_array<unsigned char>(wc, "%auc", 17);
+        test_array<int16_t>(wc, "%ahd", -17);        test_array<uint16_t>(wc, "%auhd", 17);
+        test_array<int32_t>(wc, "%ad", -17);         test_array<uint32_t>(wc, "%aud", 17);
+        test_array<int64_t>(wc, "%ald", -17);        test_array<uint64_t>(wc, "%auld", 17);
+        test_array<float>(wc, "%af", 123.456789f);   test_array<double>(wc, "%alf", -123.456789);
+        for (uint64_t nb : {1, 4, 16, 64}) {
+            test_sum<char>(wc, "%c", 7, nb);                 test_sum<unsigned char>(wc, "%uc", 7, nb);
+            test_sum<int16_t>(wc, "%hd", -17, nb);           test_sum<uint16_t>(wc, "%uhd", 17, nb);
+            test_sum<int32_t>(wc, "%d", -117, nb);           test_sum<uint32_t>(wc, "%ud", 117, nb);
+            test_sum<int64_t>(wc, "%ld", -177, nb);          test_sum<uint64_t>(wc, "%uld", 177, nb);
+            test_sum<float>(wc, "%f", (float)123.450, nb);   test_sum<double>(wc, "%lf", 123.45678, nb);
+        }
+        test_filters_known_answers(wc);
+        test_truncated(wc);
+    } catch (const std::exception &e) {
+        printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
+        failures++;
+    }
+    printf("%d failure(s)\n", failures);
+    return failures ? 1 : 0;
+}

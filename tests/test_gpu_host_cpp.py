@@ -1,0 +1,21 @@
+"""Runs the C++ host-layer test program (tests/host/test_packet_wave.cpp over
+mrnet_amd/host/PacketWave.h and the C ABI) the way the reference's driver runs its tests:
+execute, then look for failures in the output (tests/mrnet_tests.sh:119-130)."""
+import os
+import subprocess
+
+import pytest
+
+from wavegen import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_packet_wave_program():
+    exe = os.path.join(ROOT, "tests", "host", "test_packet_wave")
+    assert os.path.exists(exe), "build it with `make` (it travels with the tree, prebuilt)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0
+    assert "MRNTEST_FAILURE" not in r.stdout
+    assert r.stdout.count("MRNTEST_SUCCESS") >= 58
