@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--cpu-reps", type=int, default=4)
     p.add_argument("--no-cpu", action="store_true")
     p.add_argument("--no-extras", action="store_true")
+    p.add_argument("--backend", default="nccl", help="nccl (= RCCL) for the real run; gloo to rehearse "
+                                                     "several ranks on one GPU")
+    p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     return p.parse_args()
 
 
@@ -275,10 +278,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+    if a.one_device:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.backend)
     if a.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
 
@@ -310,7 +318,7 @@ def main():
     perf = codec.perf_collect()
     codec.perf_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     dec_ms = perf["decode"][0] / max(1, perf["decode"][1])
@@ -324,7 +332,7 @@ def main():
         achieved = st.bytes_copy_kernel / (dec_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and (a.packets, a.elems) == (4096, 65536):
             try:
                 traffic = json.load(open(tpath)).get("k_copy_decode_swap4_hbm_bytes_per_launch")
             except Exception:
@@ -359,6 +367,31 @@ def main():
             out["extra"] = extra
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
+    if world > 1:
+        # the one exchange step of the path: BASELINE config 5, a '%lf %d' wave of world x 131,072
+        # packets, fused Avg per shard, results all-gathered (RCCL) and folded in rank order
+        from mrnet_amd import dist as D
+        n5 = 131072
+        fmt5 = W.Format("%lf %d")
+        g5 = torch.Generator(device="cuda").manual_seed(5 + rank)
+        v = torch.randn(n5, dtype=torch.float64, device="cuda", generator=g5) * 1e-4 + 1e-3
+        rows = torch.empty((n5, 12), dtype=torch.uint8, device="cuda")
+        rows[:, :8] = v.view(torch.uint8).view(n5, 8)
+        rows[:, 8:] = torch.ones(n5, dtype=torch.int32, device="cuda").view(torch.uint8).view(n5, 4)
+        w5 = W.WireWave(rows.view(-1), n5, None, None, 12)
+        for _ in range(3):
+            res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
+        barrier()
+        t5 = time.perf_counter()
+        for _ in range(20):
+            res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
+        barrier()
+        t5 = (time.perf_counter() - t5) / 20
+        cnt5 = int(res5[8:12].view(torch.int32).item())
+        assert int(ok5.item()) == 1 and cnt5 == n5 * world, "sharded Avg lost packets"
+        if rank == 0:
+            out["extra"] = {"c5_sharded_avg_us_per_wave": round(t5 * 1e6, 1), "c5_packets": n5 * world,
+                            "c5_avg": float(res5[:8].view(torch.float64).item())}
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)

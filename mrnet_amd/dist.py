@@ -27,9 +27,12 @@ def gather_results(result, result_ok, group=None):
     packed = torch.zeros(20, dtype=torch.uint8, device=result.device)
     packed[:16] = result
     packed[16:20] = result_ok.view(torch.uint8)
+    dev = packed.device
+    if packed.is_cuda and dist.get_backend(group) == "gloo":
+        packed = packed.cpu()            # CPU rehearsal of the exchange; RCCL gathers on the device
     out = [torch.empty_like(packed) for _ in range(world)]
     dist.all_gather(out, packed, group=group)
-    rows = torch.stack(out)
+    rows = torch.stack(out).to(dev)
     return rows[:, :16].contiguous(), rows[:, 16:20].contiguous().view(torch.int32).view(-1)
 
 
