@@ -164,12 +164,11 @@ const char *mrpdr_fmt_string(const mrpdr_fmt *f);
  * lens[i] = encoded data length of packet i.  The arena layout: packet i owns a slot of
  * round_up(phase + lens[i], align) bytes and starts `phase` bytes into it, so
  * offsets[i] = (sum of the slots before i) + phase and offsets[n] = the arena size
- * (align: 1 or a power of two up to 256; phase < align; align 1 / phase 0 = packed).
+ * (align: 1 or a power of two up to 256; align 1 / phase 0 = packed).
  * Placement is free because the reference keeps every packet in its own malloc block;
  * the bytes of each packet do not change.  A phase from mrpdr_fmt_payload_phase lines
  * the array payloads up with cache lines, which the encode kernel's stores like.
- * Scalar-only formats ignore phase.  total_host (optional) receives offsets[n] and
- * synchronises the stream. */
+ * total_host (optional) receives offsets[n] and synchronises the stream. */
 int32_t mrpdr_wave_sizeof(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
                           uint64_t n, uint32_t align, uint32_t phase, uint64_t *lens,
                           uint64_t *offsets, uint64_t *total_host, void *stream);
@@ -209,14 +208,16 @@ int32_t mrpdr_wave_decode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *
  *   u32 stream_id | i32 tag | u32 src_rank | u32 strlen(fmt)+1 | fmt,NUL |
  *   u64 ndest (= 0) | u8 byteorder
  * stream_ids / tags / src_ranks are device columns; a NULL column means the scalar
- * argument applies to every packet.  Header i is written at hdrs + i*hdr_stride.
+ * argument applies to every packet.  Header i is written at hdrs + hdr_offsets[i], or at
+ * hdrs + i*hdr_stride when hdr_offsets is NULL.
  * mrpdr_header_bytes gives the header length for a format (no destination list). */
 uint64_t mrpdr_header_bytes(const mrpdr_fmt *f);
 int32_t  mrpdr_wave_encode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
                                    uint32_t stream_id, const uint32_t *stream_ids,
                                    int32_t tag, const int32_t *tags,
                                    uint32_t src_rank, const uint32_t *src_ranks,
-                                   uint8_t *hdrs, uint64_t hdr_stride, void *stream);
+                                   uint8_t *hdrs, const uint64_t *hdr_offsets, uint64_t hdr_stride,
+                                   void *stream);
 /* Packet::decode_pdr_header (src/Packet.C:87-104): byte order of a header is its own
  * last byte.  Header i is hdrs + hdr_offsets[i] (or i*hdr_stride when hdr_offsets is
  * NULL), hdr_lens[i] long (or hdr_stride when NULL).  Outputs (any may be NULL):
@@ -228,6 +229,32 @@ int32_t  mrpdr_wave_decode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t 
                                    uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
                                    uint8_t *byteorders, uint64_t *ndests, int32_t *ok,
                                    void *stream);
+
+/* ---- message framing -----------------------------------------------------------
+ * Message::send / Message::recv (src/Message.C:201-335, 48-199).  A message is
+ *   u8 byteorder | u32 npackets | 2n x u64 sizes (hdr0, buf0, hdr1, ...) | 1 spare byte |
+ *   hdr0 | buf0 | hdr1 | buf1 | ...
+ * Its payload part (everything after the preamble) IS a wave arena with interleaved headers,
+ * so a wave is encoded straight into the message buffer and decoded straight out of it:
+ *
+ *   send  lens/offsets = mrpdr_wave_sizeof(align 1, phase = mrpdr_header_bytes(f))
+ *         -> offsets[i] is the position of packet i's data in the payload, its header sits
+ *            hdr_len bytes in front of it, offsets[n] is the payload size;
+ *         mrpdr_message_write_preamble(msg);  payload = msg + mrpdr_message_preamble_bytes(n);
+ *         mrpdr_wave_encode(wire{payload, offsets, lens});
+ *         mrpdr_wave_encode_headers(hdrs = payload - hdr_len, hdr_offsets = offsets)
+ *   recv  the host reads the 5-byte count, then the size vector (as the reference does);
+ *         mrpdr_message_parse_sizes turns the size vector into hdr/buf offsets and lengths
+ *         (arrays of n+1 offsets; [n] = payload size) for mrpdr_wave_decode_headers and
+ *         mrpdr_wave_decode on the payload.
+ * The size vector is read in the local byte order, exactly like src/Message.C:117. */
+uint64_t mrpdr_message_preamble_bytes(uint64_t n);
+int32_t  mrpdr_message_write_preamble(mrpdr_ctx *ctx, uint64_t n, uint64_t hdr_len,
+                                      const uint64_t *lens, uint8_t *msg, void *stream);
+int32_t  mrpdr_message_parse_sizes(mrpdr_ctx *ctx, const uint8_t *sizes, uint64_t n,
+                                   uint64_t *hdr_offsets, uint64_t *hdr_lens,
+                                   uint64_t *buf_offsets, uint64_t *buf_lens,
+                                   uint64_t *payload_bytes_host, void *stream);
 
 /* ---- filters: tfilter_Sum / Min / Max / Avg over a wave ---------------------------
  * (src/FilterDefinitions.C:90-645; arithmetic helpers :1925-2136.)

@@ -18,14 +18,14 @@ struct HdrEncodeArgs {
     uint32_t stream_id; const uint32_t *stream_ids;
     int32_t  tag;       const int32_t  *tags;
     uint32_t src_rank;  const uint32_t *src_ranks;
-    uint8_t *hdrs; uint64_t hdr_stride; uint64_t n;
+    uint8_t *hdrs; const uint64_t *hdr_offsets; uint64_t hdr_stride; uint64_t n;
 };
 
 __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_encode(HdrEncodeArgs a, HdrImage img)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= a.n) return;
-    uint8_t *p = a.hdrs + i * a.hdr_stride;
+    uint8_t *p = a.hdrs + (a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride);
     st_u<uint32_t>(p + 0, a.stream_ids ? a.stream_ids[i] : a.stream_id);
     st_u<int32_t>(p + 4, a.tags ? a.tags[i] : a.tag);
     st_u<uint32_t>(p + 8, a.src_ranks ? a.src_ranks[i] : a.src_rank);

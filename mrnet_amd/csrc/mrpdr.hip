@@ -11,6 +11,7 @@
 #include "copy.h"
 #include "filter.h"
 #include "header.h"
+#include "message.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -376,13 +377,12 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
 {
     if (!check_common("mrpdr_wave_sizeof", c, f, n)) return 0;
     if (align == 0 || align > 256 || (align & (align - 1))) return fail("mrpdr_wave_sizeof: align must be a power of two <= 256");
-    if (phase >= align) return fail("mrpdr_wave_sizeof: phase must be smaller than align");
     if (!offsets) return fail("mrpdr_wave_sizeof: NULL offsets");
     hipStream_t st = (hipStream_t)stream;
     if (f->fixed) {
         const uint64_t len = f->dev.fixed_bytes;
-        const uint64_t stride = (len + align - 1) & ~(uint64_t)(align - 1);
-        k_offsets_fixed<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, st>>>(n, len, stride, lens, offsets);
+        const uint64_t stride = (len + phase + align - 1) & ~(uint64_t)(align - 1);
+        k_offsets_fixed<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, st>>>(n, len, stride, phase, lens, offsets);
         LAUNCHED("k_offsets_fixed");
         if (total_host) *total_host = n * stride;
         return 1;
@@ -589,15 +589,16 @@ extern "C" int32_t mrpdr_wave_encode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
                                              uint32_t stream_id, const uint32_t *stream_ids,
                                              int32_t tag, const int32_t *tags,
                                              uint32_t src_rank, const uint32_t *src_ranks,
-                                             uint8_t *hdrs, uint64_t hdr_stride, void *stream)
+                                             uint8_t *hdrs, const uint64_t *hdr_offsets, uint64_t hdr_stride,
+                                             void *stream)
 {
     if (!c) return fail("mrpdr_wave_encode_headers: NULL ctx");
     HdrImage img;
     if (!make_image("mrpdr_wave_encode_headers", f, &img)) return 0;
-    if (hdr_stride < mrpdr_header_bytes(f)) return fail("mrpdr_wave_encode_headers: stride shorter than the header");
+    if (!hdr_offsets && hdr_stride < mrpdr_header_bytes(f)) return fail("mrpdr_wave_encode_headers: stride shorter than the header");
     if (n == 0) return 1;
     if (!hdrs) return fail("mrpdr_wave_encode_headers: NULL output");
-    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, hdrs, hdr_stride, n };
+    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, hdrs, hdr_offsets, hdr_stride, n };
     k_hdr_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
     LAUNCHED("k_hdr_encode");
     return 1;
@@ -619,6 +620,46 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
                         byteorders, ndests, ok, n };
     k_hdr_decode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
     LAUNCHED("k_hdr_decode");
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
+// message framing
+// ---------------------------------------------------------------------------
+extern "C" uint64_t mrpdr_message_preamble_bytes(uint64_t n) { return MSG_COUNT_BYTES + 16 * n + 1; }
+
+extern "C" int32_t mrpdr_message_write_preamble(mrpdr_ctx *c, uint64_t n, uint64_t hdr_len, const uint64_t *lens,
+                                                uint8_t *msg, void *stream)
+{
+    if (!c) return fail("mrpdr_message_write_preamble: NULL ctx");
+    if (!msg || (n && !lens)) return fail("mrpdr_message_write_preamble: NULL argument");
+    if (n > 0xFFFFFFFFull) return fail("mrpdr_message_write_preamble: the packet count is a uint32 on the wire");
+    k_msg_preamble<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(msg, n, hdr_len, lens);
+    LAUNCHED("k_msg_preamble");
+    return 1;
+}
+
+extern "C" int32_t mrpdr_message_parse_sizes(mrpdr_ctx *c, const uint8_t *sizes, uint64_t n,
+                                             uint64_t *hdr_offsets, uint64_t *hdr_lens,
+                                             uint64_t *buf_offsets, uint64_t *buf_lens,
+                                             uint64_t *payload_bytes_host, void *stream)
+{
+    if (!c) return fail("mrpdr_message_parse_sizes: NULL ctx");
+    if (n > c->max_packets) return fail("mrpdr_message_parse_sizes: n exceeds the ctx limit");
+    if (!hdr_offsets || !buf_offsets || (n && (!sizes || !hdr_lens || !buf_lens)))
+        return fail("mrpdr_message_parse_sizes: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n) {
+        k_msg_split<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(sizes, n, hdr_lens, buf_lens, buf_offsets);
+        LAUNCHED("k_msg_split");
+    }
+    if (!run_scan(c, buf_offsets, n, 1, 0, hdr_offsets, st)) return 0;
+    k_msg_place<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, st>>>(hdr_offsets, hdr_lens, n, buf_offsets);
+    LAUNCHED("k_msg_place");
+    if (payload_bytes_host) {
+        HIP_OK(hipMemcpyAsync(payload_bytes_host, hdr_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+    }
     return 1;
 }
 

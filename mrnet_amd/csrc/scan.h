@@ -153,9 +153,9 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
 
 // Packed layout of a fixed-length format: closed form, no scan needed.
 __global__ __launch_bounds__(MRPDR_TPB) void k_offsets_fixed(uint64_t n, uint64_t len, uint64_t stride,
-                                                             uint64_t *lens, uint64_t *offsets)
+                                                             uint32_t phase, uint64_t *lens, uint64_t *offsets)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i < n && lens) lens[i] = len;
-    if (i <= n && offsets) offsets[i] = i * stride;
+    if (i <= n && offsets) offsets[i] = i * stride + (i < n ? phase : 0);
 }

@@ -257,7 +257,7 @@ class PacketWave {
         const uint32_t *src = nullptr;
         if (src_ranks) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
         if (!mrpdr_wave_encode_headers(wc_.ctx, fmt_, n_, stream_id_, nullptr, tag_, nullptr, 0xFFFFFFFFu, src,
-                                       d_hdrs_.ptr<uint8_t>(), hdr_len_, wc_.stream)) throw PdrError("mrpdr_wave_encode_headers");
+                                       d_hdrs_.ptr<uint8_t>(), nullptr, hdr_len_, wc_.stream)) throw PdrError("mrpdr_wave_encode_headers");
         wc_.sync();
         have_hdrs_ = true;
     }

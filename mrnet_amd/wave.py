@@ -337,12 +337,19 @@ class Codec:
     # ---- headers ---------------------------------------------------------------------
     def encode_headers(self, fmt, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
                        src_rank=UNKNOWN_RANK, stream_ids=None, tags=None, src_ranks=None,
-                       stride=None):
+                       stride=None, out=None, out_ptr=None, offsets=None):
+        """Headers of the wave.  Default: a fresh buffer, header i at i*stride.  With out_ptr
+        (a device address) and offsets, header i goes to out_ptr + offsets[i]."""
         stride = fmt.header_bytes if stride is None else stride
-        hdrs = torch.zeros(max(n * stride, 1), dtype=torch.uint8, device=self.device)
+        if out_ptr is None:
+            hdrs = out if out is not None else torch.zeros(max(n * stride, 1), dtype=torch.uint8,
+                                                           device=self.device)
+            out_ptr = hdrs.data_ptr()
+        else:
+            hdrs = out
         r = self._lib.mrpdr_wave_encode_headers(self.handle, fmt.handle, n, stream_id, _ptr(stream_ids),
                                                 tag, _ptr(tags), src_rank, _ptr(src_ranks),
-                                                _ptr(hdrs), stride, _stream())
+                                                out_ptr, _ptr(offsets), stride, _stream())
         _check(r, "mrpdr_wave_encode_headers")
         return hdrs, stride
 
@@ -359,6 +366,43 @@ class Codec:
                                                 _ptr(out["ok"]), _stream())
         _check(r, "mrpdr_wave_decode_headers")
         return out
+
+    # ---- message framing (src/Message.C:48-393) -------------------------------------------
+    def message_build(self, fmt, cols, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
+                      src_rank=UNKNOWN_RANK, src_ranks=None):
+        """One Message holding the wave, encoded in place: returns the uint8 device tensor that a
+        single writev would put on the link."""
+        h = fmt.header_bytes
+        lens, offsets, payload = self.sizeof(fmt, cols, n, 1, h)
+        pre = int(self._lib.mrpdr_message_preamble_bytes(n))
+        msg = torch.zeros(pre + payload, dtype=torch.uint8, device=self.device)
+        _check(self._lib.mrpdr_message_write_preamble(self.handle, n, h, _ptr(lens), _ptr(msg), _stream()),
+               "mrpdr_message_write_preamble")
+        wire = WireWave(msg[pre:], n, offsets, lens, 0)
+        self.encode_into(fmt, cols, wire)
+        self.encode_headers(fmt, n, stream_id=stream_id, tag=tag, src_rank=src_rank, src_ranks=src_ranks,
+                            out=msg, out_ptr=msg.data_ptr() + pre - h, offsets=offsets)
+        return msg
+
+    def message_parse(self, fmt, msg):
+        """Message -> (header fields, WireWave of the data buffers).  The 5-byte count is read on
+        the host, as Message::recv does before it knows how much more to receive."""
+        head = msg[:5].cpu().numpy()
+        bo = int(head[0])
+        n = int(head[1:5].view(">u4" if bo == BIGENDIAN else "<u4")[0])
+        pre = int(self._lib.mrpdr_message_preamble_bytes(n))
+        hdr_offs, buf_offs = self.empty(n + 1, torch.int64), self.empty(n + 1, torch.int64)
+        hdr_lens, buf_lens = self.empty(n, torch.int64), self.empty(n, torch.int64)
+        total = C.c_uint64(0)
+        r = self._lib.mrpdr_message_parse_sizes(self.handle, msg.data_ptr() + 5, n, _ptr(hdr_offs),
+                                                _ptr(hdr_lens), _ptr(buf_offs), _ptr(buf_lens),
+                                                C.byref(total), _stream())
+        _check(r, "mrpdr_message_parse_sizes")
+        if pre + total.value > msg.numel():
+            raise PdrError("message shorter than its size vector announces")
+        payload = msg[pre:pre + total.value]
+        hdr = self.decode_headers(fmt, n, payload, offsets=hdr_offs, lens=hdr_lens)
+        return n, hdr, WireWave(payload, n, buf_offs, buf_lens, 0)
 
     # ---- filters -----------------------------------------------------------------------
     def filter_raw(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,

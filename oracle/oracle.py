@@ -91,6 +91,10 @@ def lib():
         L.orc_filter_flat.restype = C.c_int32
         L.orc_filter_tree.argtypes = [C.c_int, C.c_int, vp, vp, C.c_uint64, vp, C.c_int, vp, i32p]
         L.orc_filter_tree.restype = C.c_int32
+        L.orc_message_build.argtypes = [C.c_uint32, vp, vp, vp, vp, vp, vp, vp, C.c_uint64]
+        L.orc_message_build.restype = C.c_uint64
+        L.orc_message_parse.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), vp, vp, vp, vp, C.c_uint32]
+        L.orc_message_parse.restype = C.c_int32
         L.orc_byte_swap.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
         L.orc_byte_swap.restype = None
         _lib = L
@@ -272,3 +276,31 @@ def filter_tree(op, t, vals, cnt, fanin):
     if not ok:
         return None
     return out[0], oc.value
+
+
+def message_build(hdr_arena, hdr_offs, hdr_lens, buf_arena, buf_offs, buf_lens):
+    """src/Message.C:201-335: the bytes one Message::send puts on the link.  The spare byte
+    behind the size vector (never written by the reference) is zero here."""
+    n = len(hdr_lens)
+    arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (hdr_arena, buf_arena)]
+    u64 = [np.ascontiguousarray(a, dtype=np.uint64) for a in (hdr_offs, hdr_lens, buf_offs, buf_lens)]
+    cap = 6 + 16 * n + int(u64[1].sum()) + int(u64[3].sum())
+    out = np.zeros(cap, dtype=np.uint8)
+    total = lib().orc_message_build(n, _ptr(arrs[0]), _ptr(u64[0]), _ptr(u64[1]), _ptr(arrs[1]),
+                                    _ptr(u64[2]), _ptr(u64[3]), _ptr(out), cap)
+    if total == 0 and cap != 0:
+        raise RuntimeError("orc_message_build failed")
+    return out[:total]
+
+
+def message_parse(msg):
+    """src/Message.C:48-199: (n, hdr_offs, hdr_lens, buf_offs, buf_lens) or None."""
+    msg = np.ascontiguousarray(msg, dtype=np.uint8)
+    cap = max(1, msg.size // 16)
+    n = C.c_uint32(0)
+    arrs = [np.zeros(cap, dtype=np.uint64) for _ in range(4)]
+    ok = lib().orc_message_parse(_ptr(msg), msg.size, C.byref(n), _ptr(arrs[0]), _ptr(arrs[1]),
+                                 _ptr(arrs[2]), _ptr(arrs[3]), cap)
+    if not ok:
+        return None
+    return (n.value,) + tuple(a[: n.value].copy() for a in arrs)

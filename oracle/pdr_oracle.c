@@ -676,6 +676,61 @@ uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *off
 }
 
 /* ======================================================================= */
+/* message framing (src/Message.C)                                         */
+/* ======================================================================= */
+uint64_t orc_message_build(uint32_t n, const char *hdr_arena, const uint64_t *hdr_offs,
+                           const uint64_t *hdr_lens, const char *buf_arena, const uint64_t *buf_offs,
+                           const uint64_t *buf_lens, char *out, uint64_t cap)
+{                                                                   /* src/Message.C:250-327 */
+    const uint64_t nbuf = 2ull * n;
+    const uint64_t sizes_len = nbuf * sizeof(uint64_t) + 1;           /* "1 extra bytes overhead" */
+    uint64_t total = 5 + sizes_len;
+    for (uint32_t i = 0; i < n; i++) total += hdr_lens[i] + buf_lens[i];
+    if (total > cap) return 0;
+    uint64_t *sizes = (uint64_t *)malloc((nbuf ? nbuf : 1) * sizeof(uint64_t));
+    for (uint32_t i = 0; i < n; i++) { sizes[2 * i] = hdr_lens[i]; sizes[2 * i + 1] = buf_lens[i]; }
+    orc_stream s;
+    uint32_t count = n;
+    orc_mem_create(&s, out + 1, 4, ORC_ENCODE, orc_local_bo());      /* packet count, :308-312 */
+    orc_i32(&s, &count);
+    out[0] = (char)orc_local_bo();
+    orc_mem_create(&s, out + 5, sizes_len, ORC_ENCODE, orc_local_bo());   /* packet sizes, :316-322 */
+    int32_t rc = orc_vector(&s, (char *)sizes, nbuf, sizeof(uint64_t), orc_i64);
+    free(sizes);
+    if (!rc) return 0;
+    char *p = out + 5 + sizes_len;                                    /* the writev gather, :294-299 */
+    for (uint32_t i = 0; i < n; i++) {
+        memcpy(p, hdr_arena + hdr_offs[i], (size_t)hdr_lens[i]); p += hdr_lens[i];
+        memcpy(p, buf_arena + buf_offs[i], (size_t)buf_lens[i]); p += buf_lens[i];
+    }
+    return total;
+}
+
+int32_t orc_message_parse(const char *msg, uint64_t msg_len, uint32_t *n, uint64_t *hdr_offs,
+                          uint64_t *hdr_lens, uint64_t *buf_offs, uint64_t *buf_lens, uint32_t cap_n)
+{                                                                   /* src/Message.C:71-143 */
+    if (msg_len < 5) return 0;
+    orc_stream s;
+    uint32_t count = 0;
+    orc_mem_create(&s, (char *)msg + 1, 4, ORC_DECODE, msg[0]);       /* count: the sender's flag, :78 */
+    if (!orc_i32(&s, &count)) return 0;
+    *n = count;
+    if (count > cap_n) return 0;
+    const uint64_t nbuf = 2ull * count, sizes_len = nbuf * sizeof(uint64_t) + 1;
+    if (msg_len < 5 + sizes_len) return 0;
+    uint64_t *sizes = (uint64_t *)malloc((nbuf ? nbuf : 1) * sizeof(uint64_t));
+    orc_mem_create(&s, (char *)msg + 5, sizes_len, ORC_DECODE, orc_local_bo());   /* LOCAL order, :117 */
+    int32_t rc = orc_vector(&s, (char *)sizes, nbuf, sizeof(uint64_t), orc_i64);
+    uint64_t at = 5 + sizes_len;
+    for (uint32_t i = 0; rc && i < count; i++) {
+        hdr_offs[i] = at; hdr_lens[i] = sizes[2 * i];     at += sizes[2 * i];
+        buf_offs[i] = at; buf_lens[i] = sizes[2 * i + 1]; at += sizes[2 * i + 1];
+    }
+    free(sizes);
+    return rc && at <= msg_len;
+}
+
+/* ======================================================================= */
 /* filters (src/FilterDefinitions.C)                                       */
 /* ======================================================================= */
 typedef union { char c; unsigned char uc; int16_t hd; uint16_t uhd; int32_t d; uint32_t ud;

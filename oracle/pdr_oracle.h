@@ -147,6 +147,17 @@ uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *off
                          const uint64_t *lens, uint64_t n, int sender_bo,
                          orc_column *cols, int32_t *ok);
 
+/* ---- message framing (src/Message.C:201-335 send, :48-199 recv) -------------------- */
+/* Gathers n (header, buffer) pairs into one message the way Message::send hands them to writev.
+ * The spare byte behind the size vector is left untouched, as in the reference.  Returns the
+ * message length, 0 on failure. */
+uint64_t orc_message_build(uint32_t n, const char *hdr_arena, const uint64_t *hdr_offs,
+                           const uint64_t *hdr_lens, const char *buf_arena, const uint64_t *buf_offs,
+                           const uint64_t *buf_lens, char *out, uint64_t cap);
+/* Splits a message: positions (inside msg) and lengths of every header and buffer. */
+int32_t orc_message_parse(const char *msg, uint64_t msg_len, uint32_t *n, uint64_t *hdr_offs,
+                          uint64_t *hdr_lens, uint64_t *buf_offs, uint64_t *buf_lens, uint32_t cap_n);
+
 /* ---- filters (src/FilterDefinitions.C:90-645, 1925-2136) ---------------- */
 enum orc_filter_op { ORC_SUM = 0, ORC_MIN = 1, ORC_MAX = 2, ORC_AVG = 3 };
 /*

@@ -1,0 +1,88 @@
+"""Message framing (src/Message.C): a wave encoded in place inside one message buffer, and the
+reverse.  Bar: bit-exact against the oracle's message bytes."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O, columns_equal, make_wave
+from test_gpu_codec import dev_cols, host_cols
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+
+FORMATS = ["%d", "%lf %d", "%d %s %auc", "%af", "%s", "%c %ahd %uld", "%hd %c"]
+
+
+def oracle_message(fmt_s, ocols, n, stream_id, tag, ranks):
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    hdrs = [O.header_encode(stream_id, tag, int(ranks[i]), fmt_s) for i in range(n)]
+    h = len(hdrs[0]) if n else 0
+    harena = np.concatenate(hdrs) if n else np.zeros(0, np.uint8)
+    return O.message_build(harena, np.arange(n, dtype=np.uint64) * np.uint64(h),
+                           np.full(n, h, np.uint64), arena, offs[:n], lens), arena, offs, lens
+
+
+@pytest.mark.parametrize("fmt_s", FORMATS)
+@pytest.mark.parametrize("n", [0, 1, 3, 300, 4097])
+def test_message_build_matches_oracle(codec, fmt_s, n):
+    ocols = make_wave(fmt_s, n, seed=5 * n + len(fmt_s), max_count=41)
+    ranks = (np.arange(n, dtype=np.uint32) * 7 + 3).astype(np.uint32)
+    ref, _, _, _ = oracle_message(fmt_s, ocols, n, 1 << 30, 123, ranks)
+    fmt = W.Format(fmt_s)
+    msg = codec.message_build(fmt, dev_cols(codec, fmt, ocols), n, stream_id=1 << 30, tag=123,
+                              src_ranks=codec.to_device(ranks) if n else None)
+    torch.cuda.synchronize()
+    got = W.Codec.to_numpy(msg)
+    assert got.size == ref.size
+    assert np.array_equal(got, ref), "message bytes differ"     # spare byte: 0 on both sides
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("fmt_s", FORMATS)
+@pytest.mark.parametrize("n", [0, 1, 3, 300, 4097])
+def test_message_parse_and_decode(codec, fmt_s, n):
+    ocols = make_wave(fmt_s, n, seed=11 * n + len(fmt_s), max_count=29)
+    ranks = (np.arange(n, dtype=np.uint32) + 100).astype(np.uint32)
+    ref, arena, offs, lens = oracle_message(fmt_s, ocols, n, (1 << 30) + 2, -7, ranks)
+    parsed = O.message_parse(ref)
+    fmt = W.Format(fmt_s)
+    cnt, hdr, wire = codec.message_parse(fmt, codec.to_device(ref))
+    assert cnt == n == parsed[0]
+    pre = 6 + 16 * n
+    assert np.array_equal(W.Codec.to_numpy(wire.offsets).view(np.uint64)[:n] + np.uint64(pre), parsed[3])
+    assert np.array_equal(W.Codec.to_numpy(wire.lens).view(np.uint64), parsed[4])
+    assert W.Codec.to_numpy(hdr["ok"]).tolist() == [1] * n
+    assert np.array_equal(W.Codec.to_numpy(hdr["src_rank"]).view(np.uint32), ranks)
+    assert np.array_equal(W.Codec.to_numpy(hdr["tag"]), np.full(n, -7, np.int32))
+    assert np.array_equal(W.Codec.to_numpy(hdr["stream_id"]).view(np.uint32),
+                          np.full(n, (1 << 30) + 2, np.uint32))
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    torch.cuda.synchronize()
+    assert W.Codec.to_numpy(ok).tolist() == [1] * n
+    assert columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+def test_message_round_trip_large(codec):
+    """Full-size property: build -> parse -> decode returns the columns (1024 packets x 64 KiB)."""
+    n, cnt = 1024, 16384
+    fmt = W.Format("%af")
+    vals = torch.arange(n * cnt, dtype=torch.float32, device=codec.device)
+    counts = torch.full((n,), cnt, dtype=torch.int64, device=codec.device)
+    offs = torch.arange(n + 1, dtype=torch.int64, device=codec.device) * cnt
+    msg = codec.message_build(fmt, [W.Column(vals, counts, offs, capacity=n * cnt)], n)
+    got_n, hdr, wire = codec.message_parse(fmt, msg)
+    assert got_n == n and int(hdr["ok"].sum()) == n
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert int(ok.sum()) == n
+    assert torch.equal(dcols[0].values[:n * cnt].view(torch.float32), vals)
+    assert torch.equal(dcols[0].counts.view(torch.int64), counts)
+
+
+def test_message_truncated_is_rejected(codec):
+    fmt_s = "%d %s"
+    ocols = make_wave(fmt_s, 4, seed=2, max_count=9)
+    ref, _, _, _ = oracle_message(fmt_s, ocols, 4, 1 << 30, 100, np.zeros(4, np.uint32))
+    with pytest.raises(W.PdrError):
+        codec.message_parse(W.Format(fmt_s), codec.to_device(ref[:-3]))
+    assert O.message_parse(ref[:-3]) is None

@@ -214,3 +214,32 @@ def test_filter_semantics_wrap_nan_avg():
     assert O.filter_tree(O.SUM, O.FLOAT_T, v, None, [0])[0].tobytes() == O.filter_flat(O.SUM, O.FLOAT_T, v)[0].tobytes()
     # and a different shape changes a float sum, which is why the shape is declared
     assert O.filter_tree(O.SUM, O.FLOAT_T, v, None, [2, 0])[0] != O.filter_flat(O.SUM, O.FLOAT_T, v)[0]
+
+
+def test_message_framing_round_trip():
+    """src/Message.C: u8 byte order | u32 count | 2n x u64 sizes | spare byte | hdr0 buf0 hdr1 ..."""
+    fmt = "%d %s %auc"
+    n = 3
+    cols = make_wave(fmt, n, 21, max_count=9)
+    arena, offs, lens = O.wave_encode(fmt, cols, n)
+    hdrs = [O.header_encode(1 << 30, 100, i, fmt) for i in range(n)]
+    h = len(hdrs[0])
+    hoffs = np.arange(n, dtype=np.uint64) * np.uint64(h)
+    msg = O.message_build(np.concatenate(hdrs), hoffs, np.full(n, h, np.uint64), arena, offs[:n], lens)
+    assert msg.size == 5 + 16 * n + 1 + n * h + int(lens.sum())
+    assert msg[0] == 0 and msg[1:5].view(np.uint32)[0] == n
+    sizes = msg[5:5 + 16 * n].view(np.uint64)
+    assert sizes.tolist() == [v for i in range(n) for v in (h, int(lens[i]))]
+    parsed = O.message_parse(msg)
+    assert parsed is not None and parsed[0] == n
+    _, ho, hl, bo, bl = parsed
+    for i in range(n):
+        assert msg[int(ho[i]):int(ho[i] + hl[i])].tobytes() == hdrs[i].tobytes()
+        assert msg[int(bo[i]):int(bo[i] + bl[i])].tobytes() == arena[int(offs[i]):int(offs[i] + lens[i])].tobytes()
+    # the count honours the sender's flag, the size vector is read in local order (:78 vs :117)
+    be = msg.copy()
+    be[0] = 1
+    be[1:5] = msg[1:5][::-1]
+    assert O.message_parse(be)[0] == n
+    assert O.message_parse(msg[:-1]) is None          # truncated payload
+    assert O.message_parse(O.message_build(np.zeros(0, np.uint8), [], [], np.zeros(0, np.uint8), [], []))[0] == 0
