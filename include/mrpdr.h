@@ -88,7 +88,12 @@ typedef struct mrpdr_fmt mrpdr_fmt;
  *   array         counts[n] elements per packet, offs[n+1] = exclusive scan of counts,
  *                 values = the packed elements (16-byte aligned base)
  *   string        as an array of bytes; a string counts strlen+1 (the NUL travels)
- * capacity = number of ELEMENTS values can hold (checked on decode).
+ *   string array  (%as / %As, src/Packet.C:794-813) two levels: counts[n] = strings per
+ *                 packet, offs[n+1] over strings; string j (over the whole wave) occupies
+ *                 values[sub_offs[j] .. sub_offs[j+1]) bytes, NUL included;
+ *                 sub_counts[j] = strlen+1 (written on decode, not read on encode)
+ * capacity = number of ELEMENTS values can hold, sub_capacity = number of strings
+ * sub_counts / sub_offs (+1) can hold (both checked on decode).
  * Replaces DataElement / DataValue (include/mrnet/DataElement.h:13-108).
  */
 typedef struct mrpdr_column {
@@ -96,6 +101,9 @@ typedef struct mrpdr_column {
     uint64_t *counts;
     uint64_t *offs;
     uint64_t  capacity;
+    uint64_t *sub_counts;      /* string arrays only, else NULL */
+    uint64_t *sub_offs;
+    uint64_t  sub_capacity;
 } mrpdr_column;
 
 /*
@@ -125,7 +133,8 @@ int32_t     mrpdr_local_byteorder(void);
  * every later call with this ctx. */
 mrpdr_ctx  *mrpdr_ctx_create(int32_t device, uint64_t max_packets);
 void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
-/* Sticky device-side status: 0 = fine, bit 0 = a decode ran out of column capacity.
+/* Sticky device-side status: 0 = fine, bit 0 = a decode ran out of column capacity
+ * (values or, for string arrays, sub_counts / sub_offs).
  * Synchronises `stream`. */
 int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
 
@@ -189,8 +198,10 @@ int32_t mrpdr_wave_encode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column
  * begin : walks every packet: scalar columns, counts[] of array/string fields and
  *         ok[i] (1 = packet decoded, 0 = truncated / oversize count; a failed packet
  *         yields zero for the failed field and all later ones), then scans counts
- *         into offs[].  totals_host (optional, one entry per field) receives the element
- *         total of every array/string field and synchronises the stream.
+ *         into offs[].  totals_host (optional, TWO entries per field: [i] and [nfields+i])
+ *         receives in [i] the element total of every array/string field (string arrays:
+ *         the number of strings) and in [nfields+i] the byte total of a string-array
+ *         field, and synchronises the stream.
  * finish: moves (and byte-reverses) the array/string payloads into values[].
  * mrpdr_wave_decode = begin + finish. */
 int32_t mrpdr_wave_decode_begin(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,

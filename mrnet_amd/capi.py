@@ -28,7 +28,8 @@ SYMBOLS = (
 class Column(C.Structure):
     """struct mrpdr_column"""
     _fields_ = [("values", C.c_void_p), ("counts", C.c_void_p), ("offs", C.c_void_p),
-                ("capacity", C.c_uint64)]
+                ("capacity", C.c_uint64), ("sub_counts", C.c_void_p), ("sub_offs", C.c_void_p),
+                ("sub_capacity", C.c_uint64)]
 
 
 class Wire(C.Structure):

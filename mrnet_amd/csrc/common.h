@@ -29,6 +29,9 @@ struct ColsDev {
     uint64_t *counts[MRPDR_MAXF];
     uint64_t *offs[MRPDR_MAXF];
     uint64_t  cap[MRPDR_MAXF];
+    uint64_t *sub_counts[MRPDR_MAXF];   // string arrays: strlen+1 of every string
+    uint64_t *sub_offs[MRPDR_MAXF];     // string arrays: byte range of every string in values
+    uint64_t  sub_cap[MRPDR_MAXF];
 };
 
 struct WireDev {
@@ -43,7 +46,18 @@ struct WireDev {
 // u32 strlen+1 for strings (src/pdr.c:295-297).
 __host__ __device__ inline uint32_t prefix_bytes(uint8_t kind)
 {
-    return kind == MRPDR_ARRAY ? 8u : (kind == MRPDR_STRING ? 4u : 0u);
+    return kind == MRPDR_SCALAR ? 0u : (kind == MRPDR_STRING ? 4u : 8u);
+}
+
+// Bytes that variable field g of packet s puts on the wire behind its length prefix.  A string
+// array is count x [u32 strlen+1 | bytes, NUL] (pdr_array over pdr_wrapstring,
+// src/Packet.C:794-813).
+__device__ inline uint64_t var_bytes(const FmtDev &fmt, const ColsDev &cols, int g, uint64_t s)
+{
+    const uint64_t cnt = cols.counts[g][s];
+    if (fmt.f[g].kind != MRPDR_STRING_ARRAY) return cnt * (uint64_t)fmt.f[g].width;
+    const uint64_t first = cols.offs[g][s];
+    return 4 * cnt + (cols.sub_offs[g][first + cnt] - cols.sub_offs[g][first]);
 }
 
 __device__ inline uint64_t pkt_off(const WireDev &w, uint64_t i)

@@ -101,7 +101,7 @@ __device__ inline uint64_t payload_pos(const FmtDev &fmt, const ColsDev &cols, i
 {
     uint64_t pos = (uint64_t)fmt.f[f].fixed_before + prefix_bytes(fmt.f[f].kind);
     for (int g = 0; g < f; g++)
-        if (fmt.f[g].kind != MRPDR_SCALAR) pos += cols.counts[g][s] * (uint64_t)fmt.f[g].width;
+        if (fmt.f[g].kind != MRPDR_SCALAR) pos += var_bytes(fmt, cols, g, s);
     return pos;
 }
 

@@ -12,6 +12,7 @@
 #include "filter.h"
 #include "header.h"
 #include "message.h"
+#include "strarr.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -51,6 +52,7 @@ struct mrpdr_fmt {
     char  *text;
     int    fixed;        // all scalar
     int    nvar;
+    int    nstrarr;      // string-array tokens
 };
 
 // Fmt2Type, src/DataElement.C:205-297
@@ -131,7 +133,7 @@ extern "C" mrpdr_fmt *mrpdr_fmt_compile(const char *fmt)
         fd.large = (uint8_t)(t >= MRPDR_CHAR_LRG_ARRAY_T);
         fd.fixed_before = fixed;
         if (fd.kind == MRPDR_SCALAR) fixed += fd.width;
-        else { fixed += fd.kind == MRPDR_STRING ? 4 : 8; f->nvar++; }
+        else { fixed += prefix_bytes(fd.kind); f->nvar++; f->nstrarr += fd.kind == MRPDR_STRING_ARRAY; }
     }
     f->dev.fixed_bytes = fixed;
     f->fixed = f->nvar == 0;
@@ -183,6 +185,9 @@ struct mrpdr_ctx {
     Partial  *partials;       // filter partials
     uint64_t  npartials;
     uint64_t *totals;         // per-field totals gathered for the host
+    uint64_t *sa_bytes;       // per-field byte totals of string arrays (accumulated by the walk)
+    uint64_t *pkt_bytes;      // string arrays: string bytes per packet, and their scan
+    uint64_t *pkt_boffs;
     ChunkDesc *desc;          // chunk descriptors of the payload kernels
     int32_t   num_cu;
     // optional timing of the payload kernels (mrpdr_ctx_perf_*)
@@ -210,7 +215,9 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     const size_t o_sums = o_totals + 256 * sizeof(uint64_t);
     const size_t o_part = o_sums + ((c->ntile_sums * sizeof(uint64_t) + 255) & ~(size_t)255);
     const size_t o_desc = (o_part + c->npartials * sizeof(Partial) + 255) & ~(size_t)255;
-    const size_t bytes = o_desc + (size_t)DESC_CAP * sizeof(ChunkDesc);
+    const size_t o_pktb = o_desc + (size_t)DESC_CAP * sizeof(ChunkDesc);
+    const size_t o_pkto = o_pktb + (((c->max_packets + 1) * sizeof(uint64_t) + 255) & ~(size_t)255);
+    const size_t bytes = o_pkto + (c->max_packets + 2) * sizeof(uint64_t);
     hipError_t e = hipMalloc((void **)&c->ws, bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, bytes);
     hipDeviceProp_t prop;
@@ -226,6 +233,9 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     c->tile_sums = (uint64_t *)(c->ws + o_sums);
     c->partials = (Partial *)(c->ws + o_part);
     c->desc = (ChunkDesc *)(c->ws + o_desc);
+    c->sa_bytes = c->totals + 128;
+    c->pkt_bytes = (uint64_t *)(c->ws + o_pktb);
+    c->pkt_boffs = (uint64_t *)(c->ws + o_pkto);
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return c;
 }
@@ -294,14 +304,11 @@ static int32_t check_common(const char *who, const mrpdr_ctx *c, const mrpdr_fmt
     if (!f) return fail("%s: NULL format", who);
     if (n > c->max_packets) return fail("%s: n=%llu exceeds the ctx limit %llu", who,
                                         (unsigned long long)n, (unsigned long long)c->max_packets);
-    for (int i = 0; i < f->dev.nf; i++)
-        if (f->dev.f[i].kind == MRPDR_STRING_ARRAY)
-            return fail("%s: string-array tokens (%%as / %%As) are not supported on the device", who);
     return 1;
 }
 
 static int32_t fill_cols(const char *who, const mrpdr_fmt *f, const mrpdr_column *cols, uint64_t n,
-                         bool need_values, ColsDev *out)
+                         bool need_values, ColsDev *out, bool need_sub = true)
 {
     memset(out, 0, sizeof *out);
     if (f->dev.nf && !cols) return fail("%s: NULL columns", who);
@@ -311,6 +318,9 @@ static int32_t fill_cols(const char *who, const mrpdr_fmt *f, const mrpdr_column
         out->counts[i] = cols[i].counts;
         out->offs[i] = cols[i].offs;
         out->cap[i] = cols[i].capacity;
+        out->sub_counts[i] = cols[i].sub_counts;
+        out->sub_offs[i] = cols[i].sub_offs;
+        out->sub_cap[i] = cols[i].sub_capacity;
         if (fd.kind == MRPDR_SCALAR) {
             if (n && !cols[i].values) return fail("%s: field %d has no values buffer", who, i);
         } else {
@@ -319,6 +329,8 @@ static int32_t fill_cols(const char *who, const mrpdr_fmt *f, const mrpdr_column
                 return fail("%s: field %d has no values buffer", who, i);
             if (((uintptr_t)cols[i].values & 15u) != 0)
                 return fail("%s: field %d values must be 16-byte aligned", who, i);
+            if (fd.kind == MRPDR_STRING_ARRAY && n && need_sub && !cols[i].sub_offs)
+                return fail("%s: field %d (string array) needs sub_offs", who, i);
         }
     }
     return 1;
@@ -494,9 +506,14 @@ extern "C" int32_t mrpdr_wave_encode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
     }
     k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
     LAUNCHED("k_walk_encode");
-    for (int i = 0; i < f->dev.nf; i++)
-        if (f->dev.f[i].kind != MRPDR_SCALAR)
+    for (int i = 0; i < f->dev.nf; i++) {
+        if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {
+            k_strarr_encode<<<blocks_for(n * 64, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i);
+            LAUNCHED("k_strarr_encode");
+        } else if (f->dev.f[i].kind != MRPDR_SCALAR) {
             if (!copy_field<true>(c, f, wd, cd, i, n, false, st)) return 0;
+        }
+    }
     return 1;
 }
 
@@ -512,12 +529,13 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
         return fail("mrpdr_wave_decode_begin: bad byte order %d", sender_bo);
     ColsDev cd;
     WireDev wd;
-    if (!fill_cols("mrpdr_wave_decode_begin", f, cols, n, false, &cd)) return 0;
+    if (!fill_cols("mrpdr_wave_decode_begin", f, cols, n, false, &cd, false)) return 0;
     if (!fill_wire("mrpdr_wave_decode_begin", f, wire, n, &wd)) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
-    if (totals_host) memset(totals_host, 0, sizeof(uint64_t) * (size_t)f->dev.nf);
+    if (totals_host) memset(totals_host, 0, 2 * sizeof(uint64_t) * (size_t)f->dev.nf);
     if (f->dev.nf == 0) return 1;
+    if (f->nstrarr) HIP_OK(hipMemsetAsync(c->sa_bytes, 0, MRPDR_MAXF * sizeof(uint64_t), st));
     if (n) {
         if (rows_path_ok(f, wd)) {
             const size_t lds = ROWS_PER_BLOCK * wd.stride;
@@ -525,8 +543,8 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
             else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             LAUNCHED("k_rows_decode");
         } else {
-            if (swap) k_walk_decode<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok);
-            else      k_walk_decode<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok);
+            if (swap) k_walk_decode<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, c->sa_bytes);
+            else      k_walk_decode<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, c->sa_bytes);
             LAUNCHED("k_walk_decode");
         }
     }
@@ -534,8 +552,12 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_SCALAR) continue;
         if (!run_scan(c, cd.counts[i], n, 1, 0, cd.offs[i], st)) return 0;
-        if (totals_host)
+        if (totals_host) {
             HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            if (f->dev.f[i].kind == MRPDR_STRING_ARRAY)
+                HIP_OK(hipMemcpyAsync(&totals_host[f->dev.nf + i], c->sa_bytes + i, sizeof(uint64_t),
+                                      hipMemcpyDeviceToHost, st));
+        }
     }
     if (totals_host) HIP_OK(hipStreamSynchronize(st));
     return 1;
@@ -552,9 +574,20 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     if (!fill_wire("mrpdr_wave_decode_finish", f, wire, n, &wd)) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
-    for (int i = 0; i < f->dev.nf; i++)
-        if (f->dev.f[i].kind != MRPDR_SCALAR)
+    for (int i = 0; i < f->dev.nf; i++) {
+        if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {
+            if (!cd.sub_counts[i]) return fail("mrpdr_wave_decode_finish: field %d (string array) needs sub_counts", i);
+            if (swap) k_strarr_sizes<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_bytes, c->status);
+            else      k_strarr_sizes<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_bytes, c->status);
+            LAUNCHED("k_strarr_sizes");
+            if (!run_scan(c, c->pkt_bytes, n, 1, 0, c->pkt_boffs, st)) return 0;
+            if (swap) k_strarr_decode<true><<<blocks_for(n * 64, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_boffs, c->status);
+            else      k_strarr_decode<false><<<blocks_for(n * 64, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_boffs, c->status);
+            LAUNCHED("k_strarr_decode");
+        } else if (f->dev.f[i].kind != MRPDR_SCALAR) {
             if (!copy_field<false>(c, f, wd, cd, i, n, swap, st)) return 0;
+        }
+    }
     return 1;
 }
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_size(FmtDev fmt, ColsDev cols, ui
     if (i >= n) return;
     uint64_t len = fmt.fixed_bytes;
     for (int f = 0; f < fmt.nf; f++)
-        if (fmt.f[f].kind != MRPDR_SCALAR) len += cols.counts[f][i] * (uint64_t)fmt.f[f].width;
+        if (fmt.f[f].kind != MRPDR_SCALAR) len += var_bytes(fmt, cols, f, i);
     lens[i] = len;
 }
 
@@ -113,9 +113,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev w
 // (src/pdr.c:224,429), array elements are checked one by one so the array fails when
 // count*width exceeds the space (src/pdr.c:459-462).  After the first failure the
 // remaining fields of that packet read as zero.
+// String arrays: the lane walks the strings of its packet (their lengths are on the wire one
+// behind the other), counts[] receives the number of strings and sa_bytes[f] accumulates the
+// bytes of all strings of field f over the wave (what the caller sizes values[] with).
 template <bool SWAP>
 __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev wire, ColsDev cols,
-                                                           uint64_t n, int32_t *ok)
+                                                           uint64_t n, int32_t *ok, uint64_t *sa_bytes)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= n) return;
@@ -138,6 +141,23 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
                 const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
                 if (cnt > bound || cnt > space / w) { good = false; cnt = 0; }
                 p += cnt * w; space -= cnt * w;
+            } else good = false;
+            cols.counts[f][i] = cnt;
+        } else if (fd.kind == MRPDR_STRING_ARRAY) {
+            // u64 count, then count x [u32 strlen+1 | bytes] (src/Packet.C:794-813)
+            uint64_t cnt = 0, bytes = 0;
+            if (good && 8 <= space) {
+                cnt = ld_wire<8>(p, SWAP); p += 8; space -= 8;
+                const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
+                if (cnt > bound || cnt > space) good = false;
+                for (uint64_t k = 0; good && k < cnt; k++) {
+                    if (4 > space) { good = false; break; }
+                    const uint64_t l = ld_wire<4>(p, SWAP); p += 4; space -= 4;
+                    if (l == 0 || l > space) { good = false; break; }
+                    p += l; space -= l; bytes += l;
+                }
+                if (!good) cnt = 0;
+                else if (bytes) atomicAdd((unsigned long long *)&sa_bytes[f], (unsigned long long)bytes);
             } else good = false;
             cols.counts[f][i] = cnt;
         } else {    // MRPDR_STRING: u32 strlen+1, then the bytes, NUL included
@@ -166,10 +186,10 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_encode(FmtDev fmt, WireDev w
         if (fd.kind == MRPDR_SCALAR) {
             st_w(p, (int)w, ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + i * w, (int)w, false));
             p += w;
-        } else if (fd.kind == MRPDR_ARRAY) {
+        } else if (fd.kind == MRPDR_ARRAY || fd.kind == MRPDR_STRING_ARRAY) {
             const uint64_t cnt = cols.counts[f][i];
             st_u<uint64_t>(p, cnt);                      // pdr_uint64(count), src/pdr.c:425
-            p += 8 + cnt * w;
+            p += 8 + var_bytes(fmt, cols, f, i);
         } else {
             const uint64_t cnt = cols.counts[f][i];
             st_u<uint32_t>(p, (uint32_t)cnt);            // pdr_uint32(strlen+1), src/pdr.c:295-297

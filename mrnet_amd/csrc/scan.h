@@ -129,7 +129,7 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
                 if (SIZED) {
                     item = fmt.fixed_bytes;
                     for (int f = 0; f < fmt.nf; f++)
-                        if (fmt.f[f].kind != MRPDR_SCALAR) item += cols.counts[f][first + k] * (uint64_t)fmt.f[f].width;
+                        if (fmt.f[f].kind != MRPDR_SCALAR) item += var_bytes(fmt, cols, f, first + k);
                     lens[first + k] = item;
                 } else {
                     item = in[first + k];

@@ -38,9 +38,12 @@ inline void hip_check(hipError_t e, const char *what)
 
 // One field of a wave in host memory.  Scalars: values holds n elements.  Arrays and strings:
 // counts[i] elements in packet i (a string counts strlen+1), values holds them back to back.
+// String arrays (%as): counts[i] strings in packet i, sub_counts[j] = strlen+1 of string j of the
+// wave, values holds the bytes of all strings back to back, NULs included.
 struct HostColumn {
     std::vector<uint8_t>  values;
     std::vector<uint64_t> counts;
+    std::vector<uint64_t> sub_counts;
     template <typename T> void set_scalars(const std::vector<T> &v)
     {
         values.assign((const uint8_t *)v.data(), (const uint8_t *)(v.data() + v.size()));
@@ -50,6 +53,17 @@ struct HostColumn {
     {
         values.assign((const uint8_t *)v.data(), (const uint8_t *)(v.data() + v.size()));
         counts = cnt;
+    }
+    void set_string_arrays(const std::vector<std::vector<std::string> > &per_packet)
+    {
+        values.clear(); counts.clear(); sub_counts.clear();
+        for (const std::vector<std::string> &strs : per_packet) {
+            counts.push_back(strs.size());
+            for (const std::string &t : strs) {
+                sub_counts.push_back(t.size() + 1);
+                values.insert(values.end(), t.c_str(), t.c_str() + t.size() + 1);
+            }
+        }
     }
     template <typename T> const T *as() const { return (const T *)values.data(); }
 };
@@ -186,8 +200,14 @@ class PacketWave {
             } else {
                 out[f].counts.resize(n_);
                 d_counts_[f].download(out[f].counts.data(), 8 * n_, wc_.stream);
-                out[f].values.resize(totals_[f] * w);
-                d_values_[f].download(out[f].values.data(), totals_[f] * w, wc_.stream);
+                const bool sa = mrpdr_fmt_field_kind(fmt_, f) == MRPDR_STRING_ARRAY;
+                const uint64_t elems = sa ? totals_[nf + f] : totals_[f];
+                out[f].values.resize(elems * w);
+                d_values_[f].download(out[f].values.data(), elems * w, wc_.stream);
+                if (sa) {
+                    out[f].sub_counts.resize(totals_[f]);
+                    d_subc_[f].download(out[f].sub_counts.data(), 8 * totals_[f], wc_.stream);
+                }
             }
         }
         wc_.sync();
@@ -208,8 +228,10 @@ class PacketWave {
         d_values_ = std::vector<DeviceBuffer>(nf);
         d_counts_ = std::vector<DeviceBuffer>(nf);
         d_coffs_ = std::vector<DeviceBuffer>(nf);
+        d_subc_ = std::vector<DeviceBuffer>(nf);
+        d_subo_ = std::vector<DeviceBuffer>(nf);
         cols_.assign(nf, mrpdr_column());
-        totals_.assign(nf, 0);
+        totals_.assign(2 * nf, 0);      // [f] elements (strings for %as), [nf + f] bytes of %as
     }
 
     void upload_columns(const std::vector<HostColumn> &cols)
@@ -231,6 +253,19 @@ class PacketWave {
                 wc_.sync();     // offs is a local
                 cols_[f].counts = d_counts_[f].ptr<uint64_t>();
                 cols_[f].offs = d_coffs_[f].ptr<uint64_t>();
+                if (mrpdr_fmt_field_kind(fmt_, f) == MRPDR_STRING_ARRAY) {
+                    const uint64_t ns = offs[n_];
+                    if (cols[f].sub_counts.size() != ns) throw std::runtime_error("PacketWave: sub_counts size");
+                    std::vector<uint64_t> so(ns + 1, 0);
+                    for (uint64_t j = 0; j < ns; j++) so[j + 1] = so[j] + cols[f].sub_counts[j];
+                    totals_[nf + f] = so[ns];
+                    d_subc_[f].upload(cols[f].sub_counts.data(), 8 * ns, wc_.stream);
+                    d_subo_[f].upload(so.data(), 8 * (ns + 1), wc_.stream);
+                    wc_.sync();
+                    cols_[f].sub_counts = d_subc_[f].ptr<uint64_t>();
+                    cols_[f].sub_offs = d_subo_[f].ptr<uint64_t>();
+                    cols_[f].sub_capacity = ns;
+                }
             }
         }
     }
@@ -308,9 +343,18 @@ class PacketWave {
                                      totals_.data(), wc_.stream)) throw PdrError("mrpdr_wave_decode_begin");
         for (int f = 0; f < nf; f++)
             if (mrpdr_fmt_field_kind(fmt_, f) != MRPDR_SCALAR) {
-                d_values_[f].resize(totals_[f] * mrpdr_fmt_field_width(fmt_, f));
+                const bool sa = mrpdr_fmt_field_kind(fmt_, f) == MRPDR_STRING_ARRAY;
+                const uint64_t elems = sa ? totals_[nf + f] : totals_[f];
+                d_values_[f].resize(elems * mrpdr_fmt_field_width(fmt_, f));
                 cols_[f].values = d_values_[f].ptr<void>();
-                cols_[f].capacity = totals_[f];
+                cols_[f].capacity = elems;
+                if (sa) {
+                    d_subc_[f].resize(8 * totals_[f]);
+                    d_subo_[f].resize(8 * (totals_[f] + 1));
+                    cols_[f].sub_counts = d_subc_[f].ptr<uint64_t>();
+                    cols_[f].sub_offs = d_subo_[f].ptr<uint64_t>();
+                    cols_[f].sub_capacity = totals_[f];
+                }
             }
         if (!mrpdr_wave_decode_finish(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), wc_.stream))
             throw PdrError("mrpdr_wave_decode_finish");
@@ -332,7 +376,7 @@ class PacketWave {
     unsigned hdr_len_ = 0;
     uint64_t arena_bytes_ = 0;
     DeviceBuffer d_hdrs_, d_arena_, d_offs_, d_lens_;
-    std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_;
+    std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_, d_subc_, d_subo_;
     std::vector<mrpdr_column> cols_;
     std::vector<uint64_t> totals_;
     std::vector<uint32_t> src_ranks_;

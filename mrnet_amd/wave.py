@@ -140,12 +140,19 @@ def Fmt2Type(token):
 class Column:
     """One decoded field of a wave on the device (struct mrpdr_column)."""
 
-    def __init__(self, values=None, counts=None, offs=None, capacity=None):
+    def __init__(self, values=None, counts=None, offs=None, capacity=None, sub_counts=None, sub_offs=None,
+                 sub_capacity=None):
         self.values, self.counts, self.offs = values, counts, offs
         self.capacity = capacity if capacity is not None else (0 if values is None else values.numel())
+        # string arrays ('%as'): counts/offs number the strings of every packet, sub_counts[j] is
+        # strlen+1 of string j of the wave, values[sub_offs[j]:sub_offs[j+1]] its bytes
+        self.sub_counts, self.sub_offs = sub_counts, sub_offs
+        self.sub_capacity = sub_capacity if sub_capacity is not None else (
+            0 if sub_counts is None else sub_counts.numel())
 
     def c_struct(self):
-        return capi.Column(_ptr(self.values), _ptr(self.counts), _ptr(self.offs), self.capacity)
+        return capi.Column(_ptr(self.values), _ptr(self.counts), _ptr(self.offs), self.capacity,
+                           _ptr(self.sub_counts), _ptr(self.sub_offs), self.sub_capacity)
 
 
 class WireWave:
@@ -215,11 +222,25 @@ class Codec:
 
     def columns_from_numpy(self, fmt, cols):
         """cols: per field either a numpy array (scalar) or (counts, values) for arrays and
-        strings (string values hold every string's bytes NUL included)."""
+        strings (string values hold every string's bytes NUL included), or
+        (counts, sub_counts, values) for string arrays."""
         out = []
         for i, k in enumerate(fmt.kinds):
             if k == SCALAR:
                 out.append(Column(self.to_device(np.asarray(cols[i], dtype=fmt.np_dtype(i)))))
+            elif k == STRING_ARRAY:
+                counts, sub_counts, values = cols[i]
+                counts = np.asarray(counts, dtype=np.uint64)
+                sub_counts = np.asarray(sub_counts, dtype=np.uint64)
+                offs = np.zeros(len(counts) + 1, dtype=np.uint64)
+                np.cumsum(counts, out=offs[1:])
+                sub_offs = np.zeros(len(sub_counts) + 1, dtype=np.uint64)
+                np.cumsum(sub_counts, out=sub_offs[1:])
+                values = np.asarray(values, dtype=np.uint8)
+                out.append(Column(self.to_device(values) if values.size else self.empty(1, torch.uint8),
+                                  self.to_device(counts), self.to_device(offs), values.size,
+                                  self.to_device(sub_counts) if sub_counts.size else self.empty(1, torch.int64),
+                                  self.to_device(sub_offs), sub_counts.size))
             else:
                 counts, values = cols[i]
                 counts = np.asarray(counts, dtype=np.uint64)
@@ -283,12 +304,12 @@ class Codec:
     # ---- decode ---------------------------------------------------------------------
     def decode_begin(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN, want_totals=True):
         w = wire.c_struct()
-        totals = (C.c_uint64 * max(1, len(fmt)))()
+        totals = (C.c_uint64 * max(1, 2 * len(fmt)))()
         carr = _c_columns(cols)
         r = self._lib.mrpdr_wave_decode_begin(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
                                               carr, _ptr(ok), totals if want_totals else None, _stream())
         _check(r, "mrpdr_wave_decode_begin")
-        return [totals[i] for i in range(len(fmt))] if want_totals else None
+        return [totals[i] for i in range(2 * len(fmt))] if want_totals else None
 
     def decode_finish(self, fmt, wire, cols, sender_bo=LITTLEENDIAN):
         w = wire.c_struct()
@@ -312,7 +333,13 @@ class Codec:
         totals = self.decode_begin(fmt, wire, cols, ok, sender_bo, want_totals=not fmt.is_fixed)
         if not fmt.is_fixed:
             for i, k in enumerate(fmt.kinds):
-                if k != SCALAR:
+                if k == STRING_ARRAY:
+                    ns, nb = int(totals[i]), int(totals[len(fmt) + i])
+                    cols[i].capacity, cols[i].sub_capacity = nb, ns
+                    cols[i].values = self.empty(max(nb, 1), torch.int8)
+                    cols[i].sub_counts = self.empty(max(ns, 1), torch.int64)
+                    cols[i].sub_offs = self.empty(ns + 1, torch.int64)
+                elif k != SCALAR:
                     cols[i].capacity = int(totals[i])
                     cols[i].values = self.empty(max(int(totals[i]), 1), _STORE[fmt.widths[i]])
             self.decode_finish(fmt, wire, cols, sender_bo)

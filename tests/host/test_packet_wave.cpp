@@ -190,6 +190,33 @@ static void test_truncated(WaveContext &wc)
     end_SubTest("truncated buffer fails per packet", ok);
 }
 
+// The shape of MRNet's own PROT_NEW_FILTER message, "%s %as %auhd" (src/Network.C:1954-1955).
+static void test_string_arrays(WaveContext &wc)
+{
+    const char *fmt = "%s %as %auhd";
+    const uint64_t nb = 5;
+    std::vector<HostColumn> cols(3);
+    cols[0] = strings(nb, "libfilters.so");
+    std::vector<std::vector<std::string> > names(nb);
+    std::vector<uint64_t> nids;
+    std::vector<uint16_t> ids;
+    for (uint64_t i = 0; i < nb; i++) {
+        for (uint64_t k = 0; k < i; k++) names[i].push_back(std::string(k, 'f') + "_filter" + std::to_string(i));
+        nids.push_back(i);
+        for (uint64_t k = 0; k < i; k++) ids.push_back((uint16_t)(100 * i + k));
+    }
+    cols[1].set_string_arrays(names);
+    cols[2].set_arrays(nids, ids);
+    PacketWave sent(wc, 1, 9, fmt, cols, nb);
+    PacketWave *got = received(wc, sent);
+    std::vector<HostColumn> out;
+    bool ok = !got->has_Error() && got->unpack(fmt, out) == 0;
+    for (int f = 0; ok && f < 3; f++)
+        ok = out[f].values == cols[f].values && out[f].counts == cols[f].counts && out[f].sub_counts == cols[f].sub_counts;
+    end_SubTest("test_string_arrays(%s %as %auhd)", ok);
+    delete got;
+}
+
 int main()
 {
     try {
@@ -210,6 +237,7 @@ int main()
         }
         test_filters_known_answers(wc);
         test_truncated(wc);
+        test_string_arrays(wc);
     } catch (const std::exception &e) {
         printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
         failures++;

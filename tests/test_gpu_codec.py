@@ -16,6 +16,12 @@ def dev_cols(codec, fmt, ocols):
     for k, c in zip(fmt.kinds, ocols):
         if k == W.SCALAR:
             out.append(W.Column(codec.to_device(c["values"])))
+        elif k == W.STRING_ARRAY:
+            vals, sc = c["values"], c["sub_counts"]
+            out.append(W.Column(codec.to_device(vals) if vals.size else codec.empty(1, torch.int8),
+                                codec.to_device(c["counts"]), codec.to_device(c["offs"]), vals.size,
+                                codec.to_device(sc) if sc.size else codec.empty(1, torch.int64),
+                                codec.to_device(c["sub_offs"]), sc.size))
         else:
             vals = c["values"]
             out.append(W.Column(codec.to_device(vals) if vals.size else codec.empty(1, torch.int8),
@@ -35,6 +41,10 @@ def host_cols(fmt, dcols, n):
             d["counts"] = W.Codec.to_numpy(c.counts).view(np.uint64)
             d["offs"] = W.Codec.to_numpy(c.offs).view(np.uint64)
             tot = int(d["offs"][n])
+            if k == W.STRING_ARRAY:
+                d["sub_counts"] = W.Codec.to_numpy(c.sub_counts).view(np.uint64)[:tot].copy()
+                d["sub_offs"] = W.Codec.to_numpy(c.sub_offs).view(np.uint64)[:tot + 1].copy()
+                tot = int(d["sub_offs"][tot])
             d["values"] = (W.Codec.to_numpy(c.values).view(dt)[:tot].copy() if tot
                            else np.zeros(0, dt))
         out.append(d)
@@ -56,7 +66,8 @@ def wire_from_numpy(codec, n, arena, offs=None, lens=None, stride=0):
 
 VAR_FORMATS = ["%d %uld %lf %s %auc", "%af", "%s", "%ad %ad %alf", "%auc", "%ahd %s %ald %c",
                "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s",
-               "%Ac %Auc %Ahd %Auhd %Ad %Aud %Ald %Auld %Af %Alf", "%lf %alf %f %af %hd %ahd"]
+               "%Ac %Auc %Ahd %Auhd %Ad %Aud %Ald %Auld %Af %Alf", "%lf %alf %f %af %hd %ahd",
+               "%as", "%s %as %auhd", "%d %As %lf %as %ad"]
 FIXED_FORMATS = ["%d", "%lf %d", "%c %uc %hd %uhd %d %ud %ld %uld %f %lf", "%c", "%hd %c", "%uld",
                  "%f %f %f"]
 
@@ -246,6 +257,23 @@ def test_truncated_packets_fail_per_packet(codec):
         dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, short), bo)
         assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
         assert columns_equal(host_cols(fmt, dcols, n), ref_cols)
+    # string arrays: cut inside the strings, inside a length prefix, inside the count
+    fmt_s = "%hd %as %d"
+    ocols = make_wave(fmt_s, n, 17)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    short = lens.copy()
+    for r, k in ((0, 1), (1, 5), (2, 9), (3, 13)):
+        sel = (np.arange(n) % 7 == r)
+        short[sel] = np.minimum(short[sel], lens[sel] - np.minimum(lens[sel], np.uint64(k)))
+    short[6::7] = np.minimum(lens[6::7], np.uint64(6))
+    for bo, src in ((W.LITTLEENDIAN, arena), (W.BIGENDIAN, to_sender_order(fmt_s, arena, offs, lens))):
+        ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, short, bo)
+        assert 0 < ref_ok.sum() < n
+        fmt = W.Format(fmt_s)
+        dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, short), bo)
+        assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+        assert columns_equal(host_cols(fmt, dcols, n), ref_cols)
+    assert codec.status() == 0
     # fixed format, packed rows path, with explicit short lengths
     fmt_s = "%d %lf %hd"
     ocols = make_wave(fmt_s, n, 12)
