@@ -9,7 +9,7 @@ HOSTTEST = tests/host/test_packet_wave
 
 all: $(LIB) oracle $(HOSTTEST)
 
-$(LIB): $(SRC)/mrpdr.hip $(SRC)/common.h $(SRC)/scan.h $(SRC)/rows.h $(SRC)/copy.h $(SRC)/filter.h $(SRC)/header.h include/mrpdr.h
+$(LIB): $(SRC)/mrpdr.hip $(wildcard $(SRC)/*.h) include/mrpdr.h
 	mkdir -p mrnet_amd/lib
 	$(HIPCC) $(HIPFLAGS) -o $@ $(SRC)/mrpdr.hip
 

@@ -147,6 +147,13 @@ int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host
 int32_t     mrpdr_ctx_perf_enable(mrpdr_ctx *ctx, int32_t on);
 int32_t     mrpdr_ctx_perf_collect(mrpdr_ctx *ctx, void *stream, double *ms_sum_host,
                                    uint64_t *launches_host);
+/* Calibration: the plain copy the payload kernels are measured against -- bytes (a multiple of
+ * 16, both pointers 16-byte aligned) moved with 128-bit nontemporal loads and stores, one
+ * 16 KiB chunk per workgroup, no codec logic.  `reps` launches are timed with HIP events on
+ * `stream`; ms_avg_host receives the average launch time.  (No counterpart in the reference:
+ * it tells what this device sustains for read+write streaming.) */
+int32_t     mrpdr_ctx_perf_plain_copy(mrpdr_ctx *ctx, void *dst, const void *src, uint64_t bytes,
+                                      int32_t reps, double *ms_avg_host, void *stream);
 
 /* ---- format strings ------------------------------------------------------
  * Fmt2Type (src/DataElement.C:205-297) + the " \t\n%" tokenising of

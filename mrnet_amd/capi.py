@@ -7,13 +7,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmrpdr.so")
+# MRPDR_LIB names another build of the same library (kernel experiments); default: in-tree
+LIB_PATH = os.environ.get("MRPDR_LIB") or os.path.join(_HERE, "lib", "libmrpdr.so")
 
 # every symbol include/mrpdr.h declares
 SYMBOLS = (
     "mrpdr_version", "mrpdr_last_error", "mrpdr_local_byteorder",
     "mrpdr_ctx_create", "mrpdr_ctx_destroy", "mrpdr_ctx_status",
-    "mrpdr_ctx_perf_enable", "mrpdr_ctx_perf_collect",
+    "mrpdr_ctx_perf_enable", "mrpdr_ctx_perf_collect", "mrpdr_ctx_perf_plain_copy",
     "mrpdr_fmt_compile", "mrpdr_fmt_free", "mrpdr_fmt_nfields", "mrpdr_fmt_field_type",
     "mrpdr_fmt_field_kind", "mrpdr_fmt_field_width", "mrpdr_fmt_is_fixed",
     "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
@@ -60,6 +61,7 @@ def load():
         "mrpdr_ctx_status": (i32, [vp, vp, C.POINTER(u32)]),
         "mrpdr_ctx_perf_enable": (i32, [vp, i32]),
         "mrpdr_ctx_perf_collect": (i32, [vp, vp, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "mrpdr_ctx_perf_plain_copy": (i32, [vp, vp, vp, u64, i32, C.POINTER(C.c_double), vp]),
         "mrpdr_fmt_compile": (vp, [C.c_char_p]),
         "mrpdr_fmt_free": (None, [vp]),
         "mrpdr_fmt_nfields": (i32, [vp]),

@@ -413,3 +413,22 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_packets(CopyArgs a, FmtDev f
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// Calibration: the same streaming loop with no codec logic
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(MRPDR_TPB) void k_plain_copy(uint8_t *dst, const uint8_t *src, uint64_t bytes)
+{
+    const uint64_t base = (uint64_t)blockIdx.x * COPY_CHUNK;
+    u32x4 v[COPY_UNROLL];
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; u++) {
+        const uint64_t b = base + (uint64_t)(u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
+        if (b < bytes) v[u] = ld16<true>(src + b);
+    }
+#pragma unroll
+    for (int u = 0; u < COPY_UNROLL; u++) {
+        const uint64_t b = base + (uint64_t)(u * MRPDR_TPB + threadIdx.x) * COPY_PIECE;
+        if (b < bytes) st16<true>(dst + b, v[u]);
+    }
+}

@@ -13,6 +13,7 @@
 #include "header.h"
 #include "message.h"
 #include "strarr.h"
+#include "tile.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -53,6 +54,7 @@ struct mrpdr_fmt {
     int    fixed;        // all scalar
     int    nvar;
     int    nstrarr;      // string-array tokens
+    TileVars tv;         // the variable fields, for the tile kernels
 };
 
 // Fmt2Type, src/DataElement.C:205-297
@@ -133,9 +135,15 @@ extern "C" mrpdr_fmt *mrpdr_fmt_compile(const char *fmt)
         fd.large = (uint8_t)(t >= MRPDR_CHAR_LRG_ARRAY_T);
         fd.fixed_before = fixed;
         if (fd.kind == MRPDR_SCALAR) fixed += fd.width;
-        else { fixed += prefix_bytes(fd.kind); f->nvar++; f->nstrarr += fd.kind == MRPDR_STRING_ARRAY; }
+        else {
+            fixed += prefix_bytes(fd.kind);
+            if (f->nvar < TILE_MAXV) f->tv.field[f->nvar] = f->dev.nf - 1;
+            f->nvar++;
+            f->nstrarr += fd.kind == MRPDR_STRING_ARRAY;
+        }
     }
     f->dev.fixed_bytes = fixed;
+    f->tv.nv = f->nvar <= TILE_MAXV ? f->nvar : 0;
     f->fixed = f->nvar == 0;
     f->text = strdup(fmt);
     return f;
@@ -188,6 +196,8 @@ struct mrpdr_ctx {
     uint64_t *sa_bytes;       // per-field byte totals of string arrays (accumulated by the walk)
     uint64_t *pkt_bytes;      // string arrays: string bytes per packet, and their scan
     uint64_t *pkt_boffs;
+    uint64_t *tile_cnt;       // tile kernels: element totals per (variable field, tile)
+    uint64_t  ntile_cnt;      // tiles the workspace holds per field
     ChunkDesc *desc;          // chunk descriptors of the payload kernels
     int32_t   num_cu;
     // optional timing of the payload kernels (mrpdr_ctx_perf_*)
@@ -209,7 +219,7 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     mrpdr_ctx *c = (mrpdr_ctx *)calloc(1, sizeof *c);
     c->device = device;
     c->max_packets = max_packets ? max_packets : 1;
-    c->ntile_sums = (c->max_packets + SCAN_TILE - 1) / SCAN_TILE + 1;
+    c->ntile_sums = (c->max_packets + SIZE_PKTS - 1) / SIZE_PKTS + 1;     // SIZE_PKTS < SCAN_TILE
     c->npartials = (c->max_packets + FILTER_TILE - 1) / FILTER_TILE + 1;
     const size_t o_status = 0, o_totals = 256;
     const size_t o_sums = o_totals + 256 * sizeof(uint64_t);
@@ -217,7 +227,9 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     const size_t o_desc = (o_part + c->npartials * sizeof(Partial) + 255) & ~(size_t)255;
     const size_t o_pktb = o_desc + (size_t)DESC_CAP * sizeof(ChunkDesc);
     const size_t o_pkto = o_pktb + (((c->max_packets + 1) * sizeof(uint64_t) + 255) & ~(size_t)255);
-    const size_t bytes = o_pkto + (c->max_packets + 2) * sizeof(uint64_t);
+    c->ntile_cnt = (c->max_packets + TILE_PKTS - 1) / TILE_PKTS + 1;
+    const size_t o_tile = o_pkto + (((c->max_packets + 2) * sizeof(uint64_t) + 255) & ~(size_t)255);
+    const size_t bytes = o_tile + (size_t)TILE_MAXV * c->ntile_cnt * sizeof(uint64_t);
     hipError_t e = hipMalloc((void **)&c->ws, bytes);
     if (e == hipSuccess) e = hipMemset(c->ws, 0, bytes);
     hipDeviceProp_t prop;
@@ -236,6 +248,7 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     c->sa_bytes = c->totals + 128;
     c->pkt_bytes = (uint64_t *)(c->ws + o_pktb);
     c->pkt_boffs = (uint64_t *)(c->ws + o_pkto);
+    c->tile_cnt = (uint64_t *)(c->ws + o_tile);
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return c;
 }
@@ -287,6 +300,34 @@ extern "C" int32_t mrpdr_ctx_perf_collect(mrpdr_ctx *c, void *stream, double *ms
         launches_host[c->perf_kind[i]]++;
     }
     c->perf_used = 0;
+    return 1;
+}
+
+extern "C" int32_t mrpdr_ctx_perf_plain_copy(mrpdr_ctx *c, void *dst, const void *src, uint64_t bytes,
+                                             int32_t reps, double *ms_avg_host, void *stream)
+{
+    if (!c || !dst || !src || !ms_avg_host) return fail("mrpdr_ctx_perf_plain_copy: NULL argument");
+    if (bytes == 0 || bytes % 16 || ((uintptr_t)dst & 15u) || ((uintptr_t)src & 15u))
+        return fail("mrpdr_ctx_perf_plain_copy: bytes and both pointers must be multiples of 16");
+    if (reps < 1) return fail("mrpdr_ctx_perf_plain_copy: reps must be positive");
+    const uint64_t chunks = (bytes + COPY_CHUNK - 1) / COPY_CHUNK;
+    if (chunks > 0x7FFFFFFFull) return fail("mrpdr_ctx_perf_plain_copy: more than 32 TiB");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    k_plain_copy<<<(uint32_t)chunks, MRPDR_TPB, 0, st>>>((uint8_t *)dst, (const uint8_t *)src, bytes);   // warm-up
+    HIP_OK(hipEventRecord(e0, st));
+    for (int32_t r = 0; r < reps; r++)
+        k_plain_copy<<<(uint32_t)chunks, MRPDR_TPB, 0, st>>>((uint8_t *)dst, (const uint8_t *)src, bytes);
+    HIP_OK(hipEventRecord(e1, st));
+    LAUNCHED("k_plain_copy");
+    HIP_OK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_avg_host = (double)ms / reps;
     return 1;
 }
 
@@ -380,6 +421,29 @@ static bool rows_path_ok(const mrpdr_fmt *f, const WireDev &w)
            ((uintptr_t)w.base & 15u) == 0;
 }
 
+// Waves of short packets (a few hundred bytes on average) take the LDS-staged tile kernels.
+#define TILE_AVG_BYTES 320
+static bool tile_path_ok(const mrpdr_fmt *f, const WireDev &w, uint64_t n)
+{
+    return !f->fixed && f->nstrarr == 0 && f->nvar <= TILE_MAXV && w.offsets && w.lens && n > 0 &&
+           w.bytes / n <= TILE_AVG_BYTES;
+}
+
+static int32_t perf_begin(mrpdr_ctx *c, hipStream_t st, bool *timed)
+{
+    *timed = c->perf_on && c->perf_used < PERF_SLOTS;
+    if (*timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
+    return 1;
+}
+static int32_t perf_end(mrpdr_ctx *c, hipStream_t st, bool timed, int kind)
+{
+    if (timed) {
+        HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used + 1], st));
+        c->perf_kind[c->perf_used++] = (uint8_t)kind;
+    }
+    return 1;
+}
+
 // ---------------------------------------------------------------------------
 // sizing
 // ---------------------------------------------------------------------------
@@ -407,9 +471,11 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
         k_scan_single<true><<<1, SCAN1_TPB, 0, st>>>(nullptr, f->dev, cd, n, align, phase, lens, offsets);
         LAUNCHED("k_scan_single");
     } else {
-        k_size<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, cd, n, lens);
-        LAUNCHED("k_size");
-        if (!run_scan(c, lens, n, align, phase, offsets, st)) return 0;
+        const uint32_t blocks = blocks_for(n, SIZE_PKTS);
+        k_size_sums<<<blocks, MRPDR_TPB, 0, st>>>(f->dev, cd, n, align, phase, lens, c->tile_sums);
+        LAUNCHED("k_size_sums");
+        k_size_offs<<<blocks, MRPDR_TPB, 0, st>>>(lens, n, align, phase, c->tile_sums, offsets);
+        LAUNCHED("k_size_offs");
     }
     if (total_host) {
         HIP_OK(hipMemcpyAsync(total_host, offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -504,6 +570,13 @@ extern "C" int32_t mrpdr_wave_encode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
         LAUNCHED("k_rows_encode");
         return 1;
     }
+    if (tile_path_ok(f, wd, n)) {
+        bool timed;
+        if (!perf_begin(c, st, &timed)) return 0;
+        k_tile_encode<<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+        LAUNCHED("k_tile_encode");
+        return perf_end(c, st, timed, 1);
+    }
     k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
     LAUNCHED("k_walk_encode");
     for (int i = 0; i < f->dev.nf; i++) {
@@ -542,6 +615,18 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
             if (swap) k_rows_decode<true><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             LAUNCHED("k_rows_decode");
+        } else if (tile_path_ok(f, wd, n)) {
+            const uint32_t tiles = blocks_for(n, TILE_PKTS);
+            if (swap) k_tile_walk<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+            else      k_tile_walk<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+            LAUNCHED("k_tile_walk");
+            k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt, c->ntile_cnt);
+            LAUNCHED("k_tile_offs");
+            for (int i = 0; totals_host && i < f->dev.nf; i++)
+                if (f->dev.f[i].kind != MRPDR_SCALAR)
+                    HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+            if (totals_host) HIP_OK(hipStreamSynchronize(st));
+            return 1;
         } else {
             if (swap) k_walk_decode<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, c->sa_bytes);
             else      k_walk_decode<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, c->sa_bytes);
@@ -574,6 +659,15 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     if (!fill_wire("mrpdr_wave_decode_finish", f, wire, n, &wd)) return 0;
     hipStream_t st = (hipStream_t)stream;
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
+    if (tile_path_ok(f, wd, n)) {
+        bool timed;
+        if (!perf_begin(c, st, &timed)) return 0;
+        const uint32_t tiles = blocks_for(n, TILE_PKTS);
+        if (swap) k_tile_decode<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+        else      k_tile_decode<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+        LAUNCHED("k_tile_decode");
+        return perf_end(c, st, timed, 0);
+    }
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {
             if (!cd.sub_counts[i]) return fail("mrpdr_wave_decode_finish: field %d (string array) needs sub_counts", i);

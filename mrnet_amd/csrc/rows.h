@@ -116,16 +116,15 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev w
 // String arrays: the lane walks the strings of its packet (their lengths are on the wire one
 // behind the other), counts[] receives the number of strings and sa_bytes[f] accumulates the
 // bytes of all strings of field f over the wave (what the caller sizes values[] with).
+//
+// p points at the packet's first byte (global memory, or a copy of the wire staged in LDS).
 template <bool SWAP>
-__global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev wire, ColsDev cols,
-                                                           uint64_t n, int32_t *ok, uint64_t *sa_bytes)
+__device__ __forceinline__ bool walk_decode_packet(const FmtDev &fmt, const ColsDev &cols, uint64_t i,
+                                                   const uint8_t *p, uint64_t space, bool good,
+                                                   uint64_t *sa_bytes, uint64_t *cnt_out = nullptr,
+                                                   uint32_t cnt_stride = 0)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t at = pkt_off(wire, i);
-    uint64_t space = pkt_len(wire, fmt, i);
-    bool good = at <= wire.bytes && space <= wire.bytes - at;
-    const uint8_t *p = wire.base + at;
+    // cnt_out (optional): the count of the k-th variable field also goes to cnt_out[k * cnt_stride]
     for (int f = 0; f < fmt.nf; f++) {
         const FieldDev fd = fmt.f[f];
         const uint32_t w = fd.width;
@@ -143,6 +142,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
                 p += cnt * w; space -= cnt * w;
             } else good = false;
             cols.counts[f][i] = cnt;
+            if (cnt_out) { *cnt_out = cnt; cnt_out += cnt_stride; }
         } else if (fd.kind == MRPDR_STRING_ARRAY) {
             // u64 count, then count x [u32 strlen+1 | bytes] (src/Packet.C:794-813)
             uint64_t cnt = 0, bytes = 0;
@@ -160,6 +160,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
                 else if (bytes) atomicAdd((unsigned long long *)&sa_bytes[f], (unsigned long long)bytes);
             } else good = false;
             cols.counts[f][i] = cnt;
+            if (cnt_out) { *cnt_out = cnt; cnt_out += cnt_stride; }
         } else {    // MRPDR_STRING: u32 strlen+1, then the bytes, NUL included
             uint64_t cnt = 0;
             if (good && 4 <= space) {
@@ -168,8 +169,22 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
                 p += cnt; space -= cnt;
             } else good = false;
             cols.counts[f][i] = cnt;
+            if (cnt_out) { *cnt_out = cnt; cnt_out += cnt_stride; }
         }
     }
+    return good;
+}
+
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev wire, ColsDev cols,
+                                                           uint64_t n, int32_t *ok, uint64_t *sa_bytes)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t at = pkt_off(wire, i);
+    const uint64_t space = pkt_len(wire, fmt, i);
+    bool good = at <= wire.bytes && space <= wire.bytes - at;
+    good = walk_decode_packet<SWAP>(fmt, cols, i, wire.base + at, space, good, sa_bytes);
     if (ok) ok[i] = good ? 1 : 0;
 }
 

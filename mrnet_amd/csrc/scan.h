@@ -151,6 +151,55 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
     if (threadIdx.x == 0) out[n] = carry;
 }
 
+// Larger waves, sizing + offsets in TWO launches: every workgroup sizes SIZE_PKTS packets and
+// leaves the sum of their slots; the second launch adds up the sums in front of the workgroup
+// (a few thousand at most, read in parallel) and scans its own packets.
+#define SIZE_PKTS (MRPDR_TPB * 4)
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_size_sums(FmtDev fmt, ColsDev cols, uint64_t n, uint32_t align,
+                                                         uint32_t phase, uint64_t *lens, uint64_t *sums)
+{
+    const uint64_t first = (uint64_t)blockIdx.x * SIZE_PKTS + (uint64_t)threadIdx.x * 4;
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (first + k >= n) break;
+        uint64_t item = fmt.fixed_bytes;
+        for (int f = 0; f < fmt.nf; f++)
+            if (fmt.f[f].kind != MRPDR_SCALAR) item += var_bytes(fmt, cols, f, first + k);
+        lens[first + k] = item;
+        s += round_up_pow2(item + phase, align);
+    }
+    uint64_t total;
+    block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_size_offs(const uint64_t *lens, uint64_t n, uint32_t align,
+                                                         uint32_t phase, const uint64_t *sums, uint64_t *out)
+{
+    uint64_t s = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += MRPDR_TPB) s += sums[j];
+    uint64_t base;
+    block_exclusive_scan(s, &base);
+    const uint64_t first = (uint64_t)blockIdx.x * SIZE_PKTS + (uint64_t)threadIdx.x * 4;
+    uint64_t v[4];
+    uint64_t mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = first + k < n ? round_up_pow2(lens[first + k] + phase, align) : 0;
+        mine += v[k];
+    }
+    uint64_t total;
+    uint64_t run = base + block_exclusive_scan(mine, &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (first + k < n) out[first + k] = run + phase;
+        run += v[k];
+        if (first + k + 1 == n) out[n] = run;
+    }
+}
+
 // Packed layout of a fixed-length format: closed form, no scan needed.
 __global__ __launch_bounds__(MRPDR_TPB) void k_offsets_fixed(uint64_t n, uint64_t len, uint64_t stride,
                                                              uint32_t phase, uint64_t *lens, uint64_t *offsets)

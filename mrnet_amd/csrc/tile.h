@@ -1,0 +1,374 @@
+// Waves of SHORT variable-length packets (tens to hundreds of bytes each): LDS-staged codec.
+//
+// Reference work per packet: pdr_packet_data walks the fields one pdr_* call at a time
+// (src/Packet.C:594-845), strings and small arrays through pdr_string / pdr_bytes / pdr_array
+// (src/pdr.c:212-333, 415-472) with a malloc each.
+//
+// Here a workgroup owns a TILE of 64 consecutive packets.  In the arena those packets are
+// neighbours, and so are their elements in every values column, so both sides of the tile are
+// two short contiguous byte ranges.  The wire range is staged in LDS: global memory sees only
+// 128-bit accesses to consecutive addresses (the wire image is loaded / stored as a block, the
+// columns are read / written as blocks), and all the irregular work -- walking fields at a
+// running cursor, finding which packet a byte belongs to -- happens in LDS.
+//
+//   encode  k_tile_encode   columns -> LDS image of the tile's packets -> wire        (1 launch)
+//   decode  k_tile_walk     wire -> LDS; scalars, counts, ok, per-tile count sums     (begin)
+//           k_tile_offs     counts + tile sums -> offs[] of every variable field      (begin)
+//           k_tile_decode   wire -> LDS; payloads -> values columns                   (finish)
+//
+// A tile whose packets do not fit the LDS image (a giant packet among small ones), overlap or
+// are out of order runs the same code straight on global memory: slower, same result.
+// Formats with string arrays or more than TILE_MAXV variable fields take the generic kernels.
+#pragma once
+
+#include "common.h"
+#include "copy.h"
+#include "rows.h"
+#include "scan.h"
+
+#define TILE_PKTS 64                   // measured: 32-packet tiles are 25-45 % slower
+#define TILE_MAXV 8
+#define TILE_IMG (24 * 1024)
+#define TILE_OFFS_PKTS 1024            // packets per workgroup of k_tile_offs
+
+struct TileVars {                       // the variable fields of the format, in order
+    int32_t nv;
+    int32_t field[TILE_MAXV];
+};
+
+struct TileLds {
+    uint64_t start[TILE_PKTS + 1];      // arena offset of every packet of the tile
+    uint64_t end[TILE_PKTS];
+    uint64_t seg[TILE_MAXV][TILE_PKTS + 1];   // offs[] of every variable field, in elements
+    uint64_t vpos[TILE_MAXV][TILE_PKTS];      // position of the field's length prefix in its packet
+    int32_t  staged;
+};
+
+// Address of arena byte x: in the LDS image (the image keeps the global address modulo 16, so
+// aligned 128-bit pieces of global memory are aligned pieces of the image) or in the arena.
+template <bool STAGED>
+__device__ __forceinline__ uint8_t *tile_at(uint8_t *img, uint8_t *gbase, uint64_t lo, uint32_t mis, uint64_t x)
+{
+    return STAGED ? img + (uint32_t)(x - lo) + mis : gbase + x;
+}
+
+__device__ __forceinline__ u32x4 ld16_u(const uint8_t *p)
+{
+    u32x4 v;
+    __builtin_memcpy(&v, p, 16);
+    return v;
+}
+__device__ __forceinline__ void st16_u(uint8_t *p, u32x4 v)
+{
+    __builtin_memcpy(p, &v, 16);
+}
+
+// Packet boundaries (and, with SEGS, the offs[] of the variable fields) of the tile into LDS
+// in one round of global loads; decides whether the tile can be staged.
+template <bool SEGS>
+__device__ __forceinline__ void tile_load_meta(TileLds &m, const TileVars &tv, const WireDev &wire,
+                                               const ColsDev &cols, uint64_t p0, uint32_t np)
+{
+    const uint32_t t = threadIdx.x;
+    if (t == 0) m.staged = 1;
+    if (t < np) {
+        const uint64_t s = wire.offsets[p0 + t], l = wire.lens[p0 + t];
+        m.start[t] = s;
+        m.end[t] = s + l;
+    }
+    if (SEGS)
+        for (int v = 0; v < tv.nv; v++)
+            for (uint32_t k = t; k <= np; k += MRPDR_TPB) m.seg[v][k] = cols.offs[tv.field[v]][p0 + k];
+    __syncthreads();
+    if (t < np) {
+        const uint64_t s = m.start[t], e = m.end[t];
+        bool fine = e >= s && s <= wire.bytes && e - s <= wire.bytes - s;      // inside the arena
+        if (t + 1 < np && m.start[t + 1] < e) fine = false;                    // in order, no overlap
+        if (t == 0 && (m.end[np - 1] < s || m.end[np - 1] - s + 32 > TILE_IMG)) fine = false;   // fits the image
+        if (!fine) m.staged = 0;
+    }
+    __syncthreads();
+}
+
+// Bytes of the variable fields in front of field f in packet i of the tile.
+__device__ __forceinline__ uint64_t tile_var_before(const TileLds &m, const TileVars &tv, const FmtDev &fmt,
+                                                    int f, uint32_t i)
+{
+    uint64_t b = 0;
+    for (int v = 0; v < tv.nv && tv.field[v] < f; v++)
+        b += (m.seg[v][i + 1] - m.seg[v][i]) * (uint64_t)fmt.f[tv.field[v]].width;
+    return b;
+}
+
+// Copy of the tile's wire range into the image: aligned 128-bit pieces (the few bytes in front
+// of the first packet and behind the last one that share their 16-byte granule come along).
+// (Issuing all loads of a lane before its first store was measured: slower, it costs occupancy.)
+__device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase, uint64_t lo, uint64_t hi, uint32_t mis)
+{
+    const uint8_t *g = gbase + lo - mis;
+    const uint32_t bytes = (uint32_t)(hi - lo) + mis;
+    for (uint32_t o = threadIdx.x * 16u; o < bytes; o += MRPDR_TPB * 16u)
+        *reinterpret_cast<u32x4 *>(img + o) = *reinterpret_cast<const u32x4 *>(g + o);
+}
+
+// Payload of variable field v between the image (or the arena) and the values column, packet by
+// packet: 16 lanes take one packet -- 128-bit pieces while they fit, then the last few elements
+// one per lane.  Neighbouring packets are neighbours in the column, so the global side of a
+// wavefront is one contiguous run.  A tile that runs on global memory may hold giant packets:
+// those are left to a second pass in which all 256 lanes share one packet.
+#define TILE_BIG_PAYLOAD 4096u
+
+template <uint32_t GROUP, bool STAGED, bool ENCODE, bool SWAP, int W>
+__device__ __forceinline__ void tile_copy_run(uint8_t *w, uint8_t *d, uint64_t len, uint32_t lane)
+{
+    typedef typename UIntOf<W>::type U;
+    const uint64_t whole = len & ~(uint64_t)15;
+    for (uint64_t o = (uint64_t)lane * 16u; o < whole; o += GROUP * 16u) {
+        if (ENCODE) st16_u(w + o, ld16_any<false>(d + o));
+        else {
+            const u32x4 x = ld16_u(w + o);
+            st16_any<false>(d + o, SWAP ? swap_elems<W>(x) : x);
+        }
+    }
+    for (uint64_t o = whole + (uint64_t)lane * W; o < len; o += (uint64_t)GROUP * W) {
+        if (ENCODE) st_u<U>(w + o, ld_u<U>(d + o));
+        else {
+            U x = ld_u<U>(w + o);
+            if (SWAP) x = bswap_u(x);
+            st_u<U>(d + o, x);
+        }
+    }
+}
+
+template <bool STAGED, bool ENCODE, bool SWAP, int W>
+__device__ __forceinline__ void tile_copy_field(TileLds &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
+                                                uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
+{
+    const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
+    for (uint32_t i = g; i < np; i += MRPDR_TPB / 16) {
+        const uint64_t s_lo = m.seg[v][i] * W, len = m.seg[v][i + 1] * W - s_lo;
+        if (len == 0 || (!STAGED && len >= TILE_BIG_PAYLOAD)) continue;
+        tile_copy_run<16u, STAGED, ENCODE, SWAP, W>(
+            tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + m.vpos[v][i] + pre), dense + s_lo, len, lane);
+    }
+    if (STAGED) return;
+    for (uint32_t i = 0; i < np; i++) {
+        const uint64_t s_lo = m.seg[v][i] * W, len = m.seg[v][i + 1] * W - s_lo;
+        if (len < TILE_BIG_PAYLOAD) continue;
+        tile_copy_run<MRPDR_TPB, STAGED, ENCODE, SWAP, W>(
+            tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + m.vpos[v][i] + pre), dense + s_lo, len, threadIdx.x);
+    }
+}
+
+template <bool STAGED, bool ENCODE, bool SWAP>
+__device__ __forceinline__ void tile_copy_fields(TileLds &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
+                                                 const WireDev &wire, const ColsDev &cols, uint32_t np)
+{
+    const uint64_t lo = m.start[0];
+    const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+    for (int v = 0; v < tv.nv; v++) {
+        const int f = tv.field[v];
+        const uint32_t pre = prefix_bytes(fmt.f[f].kind);
+        uint8_t *dense = reinterpret_cast<uint8_t *>(cols.values[f]);
+        // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
+        switch (fmt.f[f].width) {
+        case 1: tile_copy_field<STAGED, ENCODE, false, 1>(m, img, wire, v, pre, dense, np, lo, mis); break;
+        case 2: tile_copy_field<STAGED, ENCODE, SWAP, 2>(m, img, wire, v, pre, dense, np, lo, mis); break;
+        case 4: tile_copy_field<STAGED, ENCODE, SWAP, 4>(m, img, wire, v, pre, dense, np, lo, mis); break;
+        default: tile_copy_field<STAGED, ENCODE, SWAP, 8>(m, img, wire, v, pre, dense, np, lo, mis); break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode
+// ---------------------------------------------------------------------------
+template <bool STAGED>
+__device__ __forceinline__ void tile_encode_body(TileLds &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
+                                                 const WireDev &wire, const ColsDev &cols, uint64_t p0, uint32_t np)
+{
+    const uint32_t t = threadIdx.x;
+    const uint64_t lo = m.start[0];
+    const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+    // where every variable field starts in its packet
+    for (uint32_t idx = t; idx < (uint32_t)tv.nv * np; idx += MRPDR_TPB) {
+        const int v = (int)(idx / np);
+        const uint32_t i = idx - (uint32_t)v * np;
+        m.vpos[v][i] = fmt.f[tv.field[v]].fixed_before + tile_var_before(m, tv, fmt, tv.field[v], i);
+    }
+    // scalars and length prefixes: one (field, packet) pair per thread, field-major so that the
+    // column reads of neighbouring lanes are neighbours
+    for (uint32_t idx = t; idx < (uint32_t)fmt.nf * np; idx += MRPDR_TPB) {
+        const int f = (int)(idx / np);
+        const uint32_t i = idx - (uint32_t)f * np;
+        const FieldDev fd = fmt.f[f];
+        const uint64_t pos = fd.fixed_before + tile_var_before(m, tv, fmt, f, i);
+        uint8_t *dst = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + pos);
+        if (fd.kind == MRPDR_SCALAR) {
+            const uint32_t w = fd.width;
+            st_w(dst, (int)w, ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + (p0 + i) * w, (int)w, false));
+        } else {
+            int v = 0;
+            while (tv.field[v] != f) v++;
+            const uint64_t cnt = m.seg[v][i + 1] - m.seg[v][i];
+            if (fd.kind == MRPDR_ARRAY) st_u<uint64_t>(dst, cnt);      // pdr_uint64(count), src/pdr.c:425
+            else                        st_u<uint32_t>(dst, (uint32_t)cnt);   // strlen+1, src/pdr.c:295-297
+        }
+    }
+    __syncthreads();
+    tile_copy_fields<STAGED, true, false>(m, img, fmt, tv, wire, cols, np);
+    if (!STAGED) return;
+    __syncthreads();
+    // image -> arena, packet by packet (16 lanes each): the bytes in front of the first 16-byte
+    // boundary and behind the last one go out one per lane, the pieces between them as aligned
+    // 128-bit stores.  Only bytes of packets are written: what lies between packets is not ours
+    // (padding of the caller's layout, or the headers of a message).
+    const uint32_t grp = t >> 4, lane = t & 15u;
+    for (uint32_t i = grp; i < np; i += MRPDR_TPB / 16) {
+        const uint64_t s = m.start[i], e = m.end[i];
+        if (e == s) continue;
+        const uint64_t a0 = s + ((0 - (uintptr_t)(wire.base + s)) & 15u);      // first boundary at or behind s
+        const uint64_t head_end = a0 < e ? a0 : e;
+        if (s + lane < head_end) wire.base[s + lane] = *tile_at<true>(img, wire.base, lo, mis, s + lane);
+        if (a0 < e) {
+            const uint64_t a1 = a0 + ((e - a0) & ~(uint64_t)15);
+            for (uint64_t x = a0 + lane * 16u; x < a1; x += 256u)
+                *reinterpret_cast<u32x4 *>(wire.base + x) =
+                    *reinterpret_cast<const u32x4 *>(tile_at<true>(img, wire.base, lo, mis, x));
+            if (a1 + lane < e) wire.base[a1 + lane] = *tile_at<true>(img, wire.base, lo, mis, a1 + lane);
+        }
+    }
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols, uint64_t n)
+{
+    __shared__ TileLds m;
+    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
+    const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
+    tile_load_meta<true>(m, tv, wire, cols, p0, np);
+    if (m.staged) tile_encode_body<true>(m, img, fmt, tv, wire, cols, p0, np);
+    else          tile_encode_body<false>(m, img, fmt, tv, wire, cols, p0, np);
+}
+
+// ---------------------------------------------------------------------------
+// decode, begin: walk
+// ---------------------------------------------------------------------------
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
+                                                         uint64_t n, int32_t *ok, uint64_t *tile_sums,
+                                                         uint64_t ntiles)
+{
+    __shared__ TileLds m;
+    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
+    const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
+    const uint32_t t = threadIdx.x;
+    tile_load_meta<false>(m, tv, wire, cols, p0, np);
+    const bool staged = m.staged != 0;
+    const uint64_t lo = m.start[0];
+    const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+    if (staged) {
+        tile_stage_in(img, wire.base, lo, m.end[np - 1], mis);
+        __syncthreads();
+    }
+    if (t >= 64) return;                        // one wavefront walks: a lane per packet
+    bool good = false;
+    if (t < np) {
+        const uint64_t at = m.start[t], space = m.end[t] - at;
+        if (staged) {
+            good = walk_decode_packet<SWAP>(fmt, cols, p0 + t, tile_at<true>(img, wire.base, lo, mis, at), space, true,
+                                            nullptr, &m.seg[0][t], TILE_PKTS + 1);
+        } else {
+            // same checks as the generic walker: the packet must lie inside the arena
+            const uint64_t len = wire.lens[p0 + t];
+            good = at <= wire.bytes && len <= wire.bytes - at;
+            good = walk_decode_packet<SWAP>(fmt, cols, p0 + t, wire.base + at, len, good, nullptr,
+                                            &m.seg[0][t], TILE_PKTS + 1);
+        }
+        if (ok) ok[p0 + t] = good ? 1 : 0;
+    }
+    // element total of every variable field over the tile (the input of the offsets scan)
+    for (int v = 0; v < tv.nv; v++) {
+        uint64_t c = t < np ? m.seg[v][t] : 0;          // left there by the walk of this lane
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor((unsigned long long)c, d, 64);
+        if (t == 0) tile_sums[(uint64_t)v * ntiles + blockIdx.x] = c;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// decode, begin: offsets of every variable field, one launch
+// ---------------------------------------------------------------------------
+// Workgroup (c, v) owns TILE_OFFS_PKTS packets of variable field v.  Its base is the sum of the
+// tile sums in front of it (read in parallel; a wave of 2^21 packets has 32,768 of them), then
+// a workgroup scan of its own counts.
+__global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev cols, uint64_t n,
+                                                         const uint64_t *tile_sums, uint64_t ntiles)
+{
+    const int v = blockIdx.y;
+    const int f = tv.field[v];
+    const uint64_t first = (uint64_t)blockIdx.x * TILE_OFFS_PKTS;
+    const uint64_t tiles_before = first / TILE_PKTS;
+    const uint64_t *sums = tile_sums + (uint64_t)v * ntiles;
+    uint64_t s = 0;
+    for (uint64_t j = threadIdx.x; j < tiles_before; j += MRPDR_TPB) s += sums[j];
+    uint64_t base;
+    block_exclusive_scan(s, &base);
+    constexpr int IPT = TILE_OFFS_PKTS / MRPDR_TPB;
+    uint64_t c[IPT];
+    uint64_t mine = 0;
+    const uint64_t at = first + (uint64_t)threadIdx.x * IPT;
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        c[k] = at + k < n ? cols.counts[f][at + k] : 0;
+        mine += c[k];
+    }
+    uint64_t total;
+    uint64_t run = base + block_exclusive_scan(mine, &total);
+#pragma unroll
+    for (int k = 0; k < IPT; k++) {
+        if (at + k < n) cols.offs[f][at + k] = run;
+        run += c[k];
+        if (at + k + 1 == n) cols.offs[f][n] = run;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// decode, finish: payloads
+// ---------------------------------------------------------------------------
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
+                                                           uint64_t n, uint32_t *status)
+{
+    __shared__ TileLds m;
+    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    __shared__ int32_t too_small;
+    const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
+    const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
+    const uint32_t t = threadIdx.x;
+    // a column too small for the wave: nothing is written, the status word says so
+    if (t == 0) too_small = 0;
+    __syncthreads();
+    if (t < (uint32_t)tv.nv && cols.offs[tv.field[t]][n] > cols.cap[tv.field[t]]) too_small = 1;
+    tile_load_meta<true>(m, tv, wire, cols, p0, np);
+    if (too_small) {
+        if (blockIdx.x == 0 && t == 0) atomicOr(status, 1u);
+        return;
+    }
+    const bool staged = m.staged != 0;
+    if (staged) {
+        const uint64_t lo = m.start[0];
+        tile_stage_in(img, wire.base, lo, m.end[np - 1], (uint32_t)((uintptr_t)(wire.base + lo) & 15u));
+    }
+    // where every variable field starts in its packet, from the counts (a packet that failed
+    // has zero counts from the failed field on, so nothing of it is moved)
+    for (uint32_t idx = t; idx < (uint32_t)tv.nv * np; idx += MRPDR_TPB) {
+        const int v = (int)(idx / np);
+        const uint32_t i = idx - (uint32_t)v * np;
+        m.vpos[v][i] = fmt.f[tv.field[v]].fixed_before + tile_var_before(m, tv, fmt, tv.field[v], i);
+    }
+    __syncthreads();
+    if (staged) tile_copy_fields<true, false, SWAP>(m, img, fmt, tv, wire, cols, np);
+    else        tile_copy_fields<false, false, SWAP>(m, img, fmt, tv, wire, cols, np);
+}

@@ -361,6 +361,14 @@ class Codec:
         _check(self._lib.mrpdr_ctx_perf_collect(self.handle, _stream(), ms, cnt), "mrpdr_ctx_perf_collect")
         return {"decode": (ms[0], cnt[0]), "encode": (ms[1], cnt[1])}
 
+    def plain_copy_ms(self, dst, src, reps=20):
+        """Average launch time of the calibration copy kernel (src -> dst, same byte count)."""
+        ms = C.c_double(0.0)
+        nbytes = src.numel() * src.element_size()
+        _check(self._lib.mrpdr_ctx_perf_plain_copy(self.handle, _ptr(dst), _ptr(src), nbytes, reps,
+                                                   C.byref(ms), _stream()), "mrpdr_ctx_perf_plain_copy")
+        return ms.value
+
     # ---- headers ---------------------------------------------------------------------
     def encode_headers(self, fmt, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
                        src_rank=UNKNOWN_RANK, stream_ids=None, tags=None, src_ranks=None,

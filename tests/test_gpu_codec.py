@@ -377,3 +377,57 @@ def test_skewed_segment_sizes(codec, fmt_s, n, giant_every, giant, small):
     be = to_sender_order(fmt_s, arena, offs, lens)
     dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, be, offs, lens), W.BIGENDIAN)
     assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+def test_short_packet_tiles_leave_gaps_alone_and_take_any_order(codec):
+    """Waves of short packets run through LDS-staged tiles of 64 packets.  Encode must write packet
+    bytes only (the bytes between packets may be a message's headers); decode must accept packets
+    that are out of order or overlapping in the arena (then the tile reads global memory)."""
+    fmt_s = "%d %s %ahd %uc %auld"
+    n = 1000
+    ocols = make_wave(fmt_s, n, 23, max_count=20)
+    for align, phase in ((1, 0), (16, 0), (8, 3), (1, 45), (64, 7)):
+        arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align, phase=phase)
+        fmt = W.Format(fmt_s)
+        cols = dev_cols(codec, fmt, ocols)
+        dlens, doffs, total = codec.sizeof(fmt, cols, n, align, phase)
+        assert total == int(offs[n]) and np.array_equal(W.Codec.to_numpy(doffs).view(np.uint64), offs)
+        buf = torch.full((max(total, 1) + 5,), 0xEE, dtype=torch.uint8, device=codec.device)
+        for shift in (0, 5):                      # arena base 16-byte aligned, and not
+            buf.fill_(0xEE)
+            wire = W.WireWave(buf[shift:shift + total], n, doffs, dlens, 0)
+            codec.encode_into(fmt, cols, wire)
+            got = W.Codec.to_numpy(wire.arena)
+            mask = np.zeros(total, bool)
+            for i in range(n):
+                mask[int(offs[i]):int(offs[i] + lens[i])] = True
+            assert np.array_equal(got[mask], arena[:total][mask]), (align, phase, shift)
+            assert bool((got[~mask] == 0xEE).all()), "bytes between packets were overwritten"
+            assert bool((W.Codec.to_numpy(buf)[:shift] == 0xEE).all())
+            dcols, ok = codec.decode(fmt, wire)
+            assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+    # packets stored in reverse order, and two packets sharing the same bytes
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    order = np.arange(n)[::-1]
+    roffs = np.zeros(n + 1, np.uint64)
+    rarena = np.zeros_like(arena)
+    pos = 0
+    for k in order:
+        roffs[k] = pos
+        rarena[pos:pos + int(lens[k])] = arena[int(offs[k]):int(offs[k] + lens[k])]
+        pos += int(lens[k])
+    roffs[n] = pos
+    for bo, src in ((W.LITTLEENDIAN, rarena), (W.BIGENDIAN, to_sender_order(fmt_s, rarena, roffs, lens))):
+        ref_cols, ref_ok = O.wave_decode(fmt_s, src, roffs, lens, bo)
+        dcols, ok = codec.decode(W.Format(fmt_s), wire_from_numpy(codec, n, src, roffs, lens), bo)
+        assert np.array_equal(W.Codec.to_numpy(ok), ref_ok) and ref_ok.all()
+        assert columns_equal(host_cols(W.Format(fmt_s), dcols, n), ref_cols)
+    soffs, slens = offs.copy(), lens.copy()
+    soffs[1::2] = soffs[0:-1:2][:len(soffs[1::2])]          # odd packets alias the even ones
+    slens[1::2] = lens[0::2][:len(slens[1::2])]
+    soffs[n] = offs[n]
+    ref_cols, ref_ok = O.wave_decode(fmt_s, arena, soffs, slens, O.LITTLE)
+    dcols, ok = codec.decode(W.Format(fmt_s), wire_from_numpy(codec, n, arena, soffs, slens))
+    assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
+    assert columns_equal(host_cols(W.Format(fmt_s), dcols, n), ref_cols)
+    assert codec.status() == 0
