@@ -133,7 +133,7 @@ int32_t     mrpdr_local_byteorder(void);
  * every later call with this ctx. */
 mrpdr_ctx  *mrpdr_ctx_create(int32_t device, uint64_t max_packets);
 void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
-/* Sticky device-side status: 0 = fine, bit 0 = a decode ran out of column capacity
+/* Sticky device-side status: 0 = fine, bit 0 = a decode (or array filter) ran out of column capacity
  * (values or, for string arrays, sub_counts / sub_offs).
  * Synchronises `stream`. */
 int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
@@ -289,6 +289,38 @@ int32_t mrpdr_wave_filter(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shap
                           const void *counts, uint64_t count_stride,
                           uint64_t n, int32_t swap,
                           void *result, int32_t *result_ok, void *stream);
+
+/* ---- array filters ----------------------------------------------------------
+ * tfilter_ArrayConcat (src/FilterDefinitions.C:649-810): the output packet carries the arrays of
+ * all input packets back to back -- which is what the decoded values column of the wave already
+ * is.  Writes the column form of that ONE packet into out: out->counts[0] = total elements,
+ * out->offs[0..1] = {0, total} (string arrays: sub_counts / sub_offs are the input's own); the
+ * caller points out->values at the input's values and encodes out with n = 1.  The reference
+ * keeps the total in a 32-bit unsigned (:655, :771-772): totals of 2^32 and more are undefined
+ * there and set status bit 1 here. */
+int32_t mrpdr_wave_array_concat(mrpdr_ctx *ctx, const mrpdr_column *in, uint64_t n,
+                                mrpdr_column *out, void *stream);
+
+/* tfilter_PerfData with aggregation SUM / MIN / MAX / AVG (src/FilterDefinitions.C:904-1239)
+ * over a decoded wave of "%ad %ad %a{uld,ld,lf}" packets: `ranks` is the column of field 0,
+ * `data` the column of field 2, type one of MRPDR_UINT64_T / MRPDR_INT64_T / MRPDR_DOUBLE_T.
+ * The data arrays are folded element by element in packet order with the reference's rules
+ * (packets without data skipped; rank[0] < 0 = an aggregate of -rank ranks; MIN starts from
+ * bytes 0xFF, the others from 0; AVG weights by the rank count and divides the first
+ * data_len(last packet) elements by the rank total).  The output packet is
+ * ([out_rank[0]], [out_len[0]], out_data[0 .. out_len[0])): out_data holds out_cap elements
+ * (a longer result sets status bit 0 and out_len 0), out_len / out_rank are device pointers.
+ *   group = 0 or >= n : one filter invocation over the n packets (a node with n children);
+ *   0 < group < n     : a two-level tree -- nodes of `group` consecutive packets, then one node
+ *                       over their outputs (the filter runs at every level, as in an MRNet
+ *                       tree: AVG divides and re-weights per level).  Needs `scratch` of
+ *                       mrpdr_perfdata_scratch_bytes(n, group, out_cap) bytes, 16-byte aligned. */
+uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap);
+int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                            const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n,
+                            uint64_t group, void *out_data, uint64_t out_cap,
+                            uint64_t *out_len, int32_t *out_rank,
+                            void *scratch, uint64_t scratch_bytes, void *stream);
 
 #ifdef __cplusplus
 }

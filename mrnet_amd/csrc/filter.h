@@ -227,3 +227,75 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t 
         write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
     }
 }
+
+// ---------------------------------------------------------------------------
+// tfilter_PerfData: element-wise Sum / Min / Max / Avg over array packets
+// ---------------------------------------------------------------------------
+// Reference: src/FilterDefinitions.C:904-1239, packets "%ad %ad %a{uld,ld,lf}" = (rank array,
+// nelems array, data array).  One invocation folds the data arrays element by element in packet
+// order; packets without data are skipped; rank[0] < 0 means "already an aggregate of -rank
+// ranks".  Literal quirks kept: the MIN accumulator starts as bytes 0xFF (UINT64_MAX, -1 for
+// int64, a NaN for double that the first '<' discards), every other one as 0 (so MAX of negative
+// data is 0); AVG adds x * nrank and divides the first data_len(LAST packet) elements by the
+// total number of ranks; the output rank array is [-total_nranks].
+//
+// One lane per element u; workgroup row g folds the packets of group g (group = all packets:
+// one invocation; smaller groups: the first level of a tree whose second level is a second
+// launch over the group results, which this kernel leaves in column form).
+struct PerfIn {
+    const int32_t  *rank_vals; const uint64_t *rank_counts; const uint64_t *rank_offs;
+    const void     *data_vals; const uint64_t *data_counts; const uint64_t *data_offs;
+    uint64_t n, group;
+};
+struct PerfOut {
+    void     *data; uint64_t stride;      // group g writes data[g * stride + u]
+    uint64_t *lens;                       // [groups] aggr_results.size() of the group
+    uint64_t *offs;                       // [groups] g * stride (column form for the next level), or NULL
+    int32_t  *ranks;                      // [groups] -total_nranks
+    uint64_t *rank_counts, *rank_offs;    // [groups] 1 / g, or NULL
+    uint32_t *status;
+};
+
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
+{
+    const uint64_t g = blockIdx.y;
+    const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint64_t i0 = g * in.group, i1 = (i0 + in.group < in.n) ? i0 + in.group : in.n;
+    const T *data = reinterpret_cast<const T *>(in.data_vals);
+    T acc;
+    __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
+    uint32_t total = 0;
+    uint64_t longest = 0, last = 0;
+#pragma unroll 4
+    for (uint64_t i = i0; i < i1; i++) {
+        const uint64_t len = in.data_counts[i];
+        last = len;
+        if (!len) continue;
+        const int32_t rank = in.rank_counts[i] ? in.rank_vals[in.rank_offs[i]] : 0;
+        const int32_t nrank = rank < 0 ? -rank : 1;
+        total += (uint32_t)nrank;
+        if (len > longest) longest = len;
+        if (u < len) {
+            const T x = data[in.data_offs[i] + u];
+            if (OP == MRPDR_SUM) acc = acc + x;
+            else if (OP == MRPDR_MIN) acc = (acc < x) ? acc : x;
+            else if (OP == MRPDR_MAX) acc = (acc > x) ? acc : x;
+            else acc = acc + x * (T)nrank;
+        }
+    }
+    if (OP == MRPDR_AVG && last && u < last) {
+        acc = acc / (T)total;          // unsigned total converted to the element type, as the reference's /=
+    }
+    if (longest > out.stride) {                    // the result does not fit: say so, write nothing
+        if (u == 0) atomicOr(out.status, 1u);
+        longest = 0;
+    }
+    if (u < longest) reinterpret_cast<T *>(out.data)[g * out.stride + u] = acc;
+    if (u == 0) {
+        out.lens[g] = longest;
+        out.ranks[g] = 0 - (int32_t)total;
+        if (out.offs) out.offs[g] = g * out.stride;
+        if (out.rank_counts) { out.rank_counts[g] = 1; out.rank_offs[g] = g; }
+    }
+}

@@ -855,3 +855,111 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
     return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
 }
+
+// ---------------------------------------------------------------------------
+// array filters
+// ---------------------------------------------------------------------------
+__global__ void k_concat_column(const uint64_t *in_offs, uint64_t n, uint64_t *out_counts, uint64_t *out_offs,
+                                uint32_t *status)
+{
+    const uint64_t total = in_offs[n];
+    out_counts[0] = total;
+    out_offs[0] = 0;
+    out_offs[1] = total;
+    if (total > 0xFFFFFFFFull) atomicOr(status, 2u);
+}
+
+extern "C" int32_t mrpdr_wave_array_concat(mrpdr_ctx *c, const mrpdr_column *in, uint64_t n,
+                                           mrpdr_column *out, void *stream)
+{
+    if (!c || !in || !out) return fail("mrpdr_wave_array_concat: NULL argument");
+    if (n > c->max_packets) return fail("mrpdr_wave_array_concat: n exceeds the ctx limit");
+    if (!in->offs || !out->counts || !out->offs) return fail("mrpdr_wave_array_concat: counts / offs missing");
+    k_concat_column<<<1, 1, 0, (hipStream_t)stream>>>(in->offs, n, out->counts, out->offs, c->status);
+    LAUNCHED("k_concat_column");
+    return 1;
+}
+
+static inline uint64_t up16(uint64_t v) { return (v + 15) & ~(uint64_t)15; }
+
+extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
+{
+    if (group == 0 || group >= n) return 0;
+    const uint64_t g = (n + group - 1) / group;
+    // data, lens, offs, rank_counts, rank_offs, ranks
+    return up16(g * out_cap * 8) + 4 * up16(g * 8) + up16(g * 4);
+}
+
+template <int OP, typename T>
+static int32_t run_perfdata(mrpdr_ctx *c, const PerfIn &in, uint64_t out_cap, void *out_data, uint64_t *out_len,
+                            int32_t *out_rank, uint8_t *scratch, hipStream_t st)
+{
+    const uint32_t xb = blocks_for(out_cap ? out_cap : 1, MRPDR_TPB);
+    if (in.group >= in.n) {
+        PerfOut o = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
+        k_perfdata<OP, T><<<dim3(xb, 1), MRPDR_TPB, 0, st>>>(in, o);
+        LAUNCHED("k_perfdata");
+        return 1;
+    }
+    const uint64_t g = (in.n + in.group - 1) / in.group;
+    uint8_t *p = scratch;
+    void *d2 = p;                       p += up16(g * out_cap * 8);
+    uint64_t *lens2 = (uint64_t *)p;    p += up16(g * 8);
+    uint64_t *offs2 = (uint64_t *)p;    p += up16(g * 8);
+    uint64_t *rcnt2 = (uint64_t *)p;    p += up16(g * 8);
+    uint64_t *roff2 = (uint64_t *)p;    p += up16(g * 8);
+    int32_t *ranks2 = (int32_t *)p;
+    PerfOut o1 = { d2, out_cap, lens2, offs2, ranks2, rcnt2, roff2, c->status };
+    k_perfdata<OP, T><<<dim3(xb, (uint32_t)g), MRPDR_TPB, 0, st>>>(in, o1);
+    LAUNCHED("k_perfdata");
+    PerfIn in2 = { ranks2, rcnt2, roff2, d2, lens2, offs2, g, g };
+    PerfOut o2 = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
+    k_perfdata<OP, T><<<dim3(xb, 1), MRPDR_TPB, 0, st>>>(in2, o2);
+    LAUNCHED("k_perfdata");
+    return 1;
+}
+
+template <typename T>
+static int32_t run_perfdata_op(mrpdr_ctx *c, int32_t op, const PerfIn &in, uint64_t out_cap, void *out_data,
+                               uint64_t *out_len, int32_t *out_rank, uint8_t *scratch, hipStream_t st)
+{
+    switch (op) {
+    case MRPDR_SUM: return run_perfdata<MRPDR_SUM, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
+    case MRPDR_MIN: return run_perfdata<MRPDR_MIN, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
+    case MRPDR_MAX: return run_perfdata<MRPDR_MAX, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
+    case MRPDR_AVG: return run_perfdata<MRPDR_AVG, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
+    }
+    return fail("mrpdr_wave_perfdata: unknown aggregation %d", op);
+}
+
+extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
+                                       const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n,
+                                       uint64_t group, void *out_data, uint64_t out_cap,
+                                       uint64_t *out_len, int32_t *out_rank,
+                                       void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    if (!c || !ranks || !data || !out_len || !out_rank) return fail("mrpdr_wave_perfdata: NULL argument");
+    if (n == 0) return fail("mrpdr_wave_perfdata: empty wave (the reference emits nothing)");
+    if (n > c->max_packets) return fail("mrpdr_wave_perfdata: n exceeds the ctx limit");
+    if (!ranks->counts || !ranks->offs || !data->counts || !data->offs)
+        return fail("mrpdr_wave_perfdata: columns need counts and offs");
+    if (out_cap && !out_data) return fail("mrpdr_wave_perfdata: NULL out_data");
+    if (group == 0 || group > n) group = n;
+    if (group < n) {
+        const uint64_t need = mrpdr_perfdata_scratch_bytes(n, group, out_cap);
+        if (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15u))
+            return fail("mrpdr_wave_perfdata: a two-level fold needs %llu bytes of 16-byte aligned scratch",
+                        (unsigned long long)need);
+        if ((n + group - 1) / group > 65535) return fail("mrpdr_wave_perfdata: more than 65535 first-level nodes");
+    }
+    PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts,
+                  data->offs, n, group };
+    hipStream_t st = (hipStream_t)stream;
+    switch (type) {
+    case MRPDR_UINT64_T: return run_perfdata_op<uint64_t>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
+    case MRPDR_INT64_T:  return run_perfdata_op<int64_t>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
+    case MRPDR_DOUBLE_T: return run_perfdata_op<double>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
+    }
+    // PerfDataMgr metrics are uint64, int64 or double (src/FilterDefinitions.C:937-953)
+    return fail("mrpdr_wave_perfdata: type %d is not a performance-data type", type);
+}

@@ -15,6 +15,9 @@ src/Packet.C:
     (error(ERR_PACKING), src/Packet.C:122-124)
   * tfilter_Sum / Max / Min / Avg return one packet with the stream id and tag of the first
     input packet and the same format (src/FilterDefinitions.C:151-221)
+  * tfilter_ArrayConcat returns one packet whose array is the arrays of all inputs back to back
+    (src/FilterDefinitions.C:649-810); tfilter_PerfData folds "%ad %ad %a{uld,ld,lf}" packets
+    element by element (src/FilterDefinitions.C:904-1239)
 """
 import numpy as np
 import torch
@@ -189,3 +192,45 @@ def tfilter_Min(ipackets, shape=W.SHAPE_TREE):
 
 def tfilter_Avg(ipackets, shape=W.SHAPE_TREE):
     return _run_filter(W.TFILTER_AVG, ipackets, shape)
+
+
+def _from_columns(ipackets, fmt, columns):
+    """One output packet with the stream id and tag of the first input, built from device columns."""
+    return PacketWave(ipackets.codec, ipackets.get_StreamId(), ipackets.get_Tag(), fmt, columns, n=1)
+
+
+def tfilter_ArrayConcat(ipackets):
+    """One '%aT' / '%as' packet holding every input array in packet order.  Formats other than a
+    single array token yield nothing, as in the reference (src/FilterDefinitions.C:764-768)."""
+    fmt = ipackets.fmt
+    if ipackets.n == 0 or ipackets.has_Error() or len(fmt) != 1 or fmt.kinds[0] not in (W.ARRAY, W.STRING_ARRAY):
+        return None
+    cols = ipackets.unpack(fmt.text)
+    if ipackets.has_Error():
+        return None
+    return _from_columns(ipackets, fmt, [ipackets.codec.array_concat(cols[0], ipackets.n)])
+
+
+_PERF_TYPES = {"%ad %ad %auld": W.DataType.UINT64_T, "%ad %ad %ald": W.DataType.INT64_T,
+               "%ad %ad %alf": W.DataType.DOUBLE_T}
+
+
+def tfilter_PerfData(ipackets, aggr_id, group=0):
+    """Element-wise aggregation of performance-data packets (rank array, nelems array, data array).
+    aggr_id: TFILTER_SUM / MIN / MAX / AVG.  group > 0 declares a two-level tree (nodes of `group`
+    children, then one node over their outputs)."""
+    fmt, codec, n = ipackets.fmt, ipackets.codec, ipackets.n
+    if n == 0 or ipackets.has_Error() or fmt.text not in _PERF_TYPES:
+        return None
+    cols = ipackets.unpack(fmt.text)
+    if ipackets.has_Error():
+        return None
+    data, out_len, out_rank = codec.filter_perfdata(aggr_id, _PERF_TYPES[fmt.text], cols[0], cols[2], n, group)
+    # output packet: ([-total_nranks], [len], data[0:len]); the length lives on the device
+    one = torch.ones(1, dtype=torch.int64, device=codec.device)
+    offs1 = torch.tensor([0, 1], dtype=torch.int64, device=codec.device)
+    nelems = out_len.to(torch.int32)
+    doffs = torch.cat([torch.zeros(1, dtype=torch.int64, device=codec.device), out_len])
+    out_cols = [W.Column(out_rank, one, offs1, 1), W.Column(nelems, one, offs1, 1),
+                W.Column(data, out_len, doffs, data.numel())]
+    return _from_columns(ipackets, fmt, out_cols)

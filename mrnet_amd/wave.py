@@ -59,7 +59,7 @@ class DataType(enum.IntEnum):
 
 LITTLEENDIAN, BIGENDIAN = 0, 1
 SCALAR, ARRAY, STRING, STRING_ARRAY = 0, 1, 2, 3
-TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3
+TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3      # operator codes of the C ABI
 SHAPE_FLAT, SHAPE_TREE = 0, 1
 TREE_FANINS = (4, 2, 2, 2, 2, 2, 2, 4, 0)
 
@@ -451,6 +451,34 @@ class Codec:
                                         _ptr(result_ok), _stream())
         _check(r, "mrpdr_wave_filter")
         return result, result_ok
+
+    # ---- array filters -------------------------------------------------------------------
+    def array_concat(self, col, n):
+        """tfilter_ArrayConcat on a decoded array field: the Column of the ONE output packet
+        (it shares the input's values; only its count and offsets are new)."""
+        out = Column(col.values, self.empty(1, torch.int64), self.empty(2, torch.int64), col.capacity,
+                     col.sub_counts, col.sub_offs, col.sub_capacity)
+        a, b = col.c_struct(), out.c_struct()
+        _check(self._lib.mrpdr_wave_array_concat(self.handle, C.byref(a), n, C.byref(b), _stream()),
+               "mrpdr_wave_array_concat")
+        return out
+
+    def filter_perfdata(self, op, dtype, ranks, data, n, group=0, out_cap=None):
+        """tfilter_PerfData (SUM/MIN/MAX/AVG) over the rank and data columns of a decoded wave.
+        Returns (out_data, out_len, out_rank) device tensors; out_cap defaults to the longest
+        possible result (one host read of the data counts)."""
+        if out_cap is None:
+            out_cap = int(data.counts.max().item()) if n else 0
+        out = self.empty(max(out_cap, 1), torch.int64)
+        out_len, out_rank = self.empty(1, torch.int64), self.empty(1, torch.int32)
+        need = int(self._lib.mrpdr_perfdata_scratch_bytes(n, group, out_cap))
+        scratch = self.empty(max(need, 16), torch.uint8) if need else None
+        a, b = ranks.c_struct(), data.c_struct()
+        r = self._lib.mrpdr_wave_perfdata(self.handle, op, int(dtype), C.byref(a), C.byref(b), n, group,
+                                          _ptr(out), out_cap, _ptr(out_len), _ptr(out_rank),
+                                          _ptr(scratch), need, _stream())
+        _check(r, "mrpdr_wave_perfdata")
+        return out, out_len, out_rank
 
     def filter_columns(self, op, dtype, values, counts=None, shape=SHAPE_TREE):
         """Filter over decoded columns: values = T[n] tensor, counts = int32[n] (AVG)."""

@@ -95,6 +95,9 @@ def lib():
         L.orc_message_build.restype = C.c_uint64
         L.orc_message_parse.argtypes = [vp, C.c_uint64, C.POINTER(C.c_uint32), vp, vp, vp, vp, C.c_uint32]
         L.orc_message_parse.restype = C.c_int32
+        L.orc_filter_perfdata.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
+        L.orc_filter_perfdata.restype = C.c_int32
         L.orc_byte_swap.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
         L.orc_byte_swap.restype = None
         _lib = L
@@ -304,3 +307,50 @@ def message_parse(msg):
     if not ok:
         return None
     return (n.value,) + tuple(a[: n.value].copy() for a in arrs)
+
+
+def filter_perfdata(op, t, ranks, data):
+    """tfilter_PerfData (src/FilterDefinitions.C:904-1239), one invocation.  ranks / data are
+    (counts, values) pairs; returns (out_rank, out_data) -- the output packet is
+    ([out_rank], [len(out_data)], out_data)."""
+    rc, rv = (np.ascontiguousarray(ranks[0], dtype=np.uint64), np.ascontiguousarray(ranks[1], dtype=np.int32))
+    dc, dv = (np.ascontiguousarray(data[0], dtype=np.uint64), np.ascontiguousarray(data[1], dtype=elem_dtype(t)))
+    ro = np.zeros(rc.size + 1, np.uint64); np.cumsum(rc, out=ro[1:])
+    do = np.zeros(dc.size + 1, np.uint64); np.cumsum(dc, out=do[1:])
+    cap = int(dc.max()) if dc.size else 0
+    out = np.zeros(max(cap, 1), dtype=elem_dtype(t))
+    olen, orank = C.c_uint64(0), C.c_int32(0)
+    ok = lib().orc_filter_perfdata(op, t, _ptr(rv), _ptr(rc), _ptr(ro), _ptr(dv), _ptr(dc), _ptr(do), dc.size,
+                                   _ptr(out), cap, C.byref(olen), C.byref(orank))
+    if not ok:
+        return None
+    return orank.value, out[: olen.value].copy()
+
+
+def filter_perfdata_tree(op, t, ranks, data, fanins):
+    """The same filter applied level by level: level L folds groups of fanins[L] consecutive
+    packets of the level below (0 = all of them); a group without data yields an empty packet."""
+    rc, rv = np.asarray(ranks[0], np.uint64), np.asarray(ranks[1], np.int32)
+    dc, dv = np.asarray(data[0], np.uint64), np.asarray(data[1], elem_dtype(t))
+    for fan in fanins:
+        m = dc.size
+        f = int(fan) if fan else max(m, 1)
+        ro = np.zeros(m + 1, np.int64); np.cumsum(rc, out=ro[1:])
+        do = np.zeros(m + 1, np.int64); np.cumsum(dc, out=do[1:])
+        nrc, nrv, ndc, ndv = [], [], [], []
+        for g in range(0, m, f):
+            h = min(m, g + f)
+            r = filter_perfdata(op, t, (rc[g:h], rv[ro[g]:ro[h]]), (dc[g:h], dv[do[g]:do[h]]))
+            orank, odata = r
+            if odata.size:
+                nrc.append(1); nrv.append(orank); ndc.append(odata.size); ndv.append(odata)
+            else:
+                nrc.append(0); ndc.append(0)
+        rc, rv = np.asarray(nrc, np.uint64), np.asarray(nrv, np.int32)
+        dc = np.asarray(ndc, np.uint64)
+        dv = np.concatenate(ndv) if ndv else np.zeros(0, elem_dtype(t))
+        if dc.size <= 1:
+            break
+    if dc.size != 1:
+        return None
+    return (int(rv[0]) if rv.size else 0), dv

@@ -911,3 +911,79 @@ int32_t orc_filter_tree(int op, int type, const void *vals, const int32_t *cnt, 
     free(v); free(c); free(present); free(gv); free(gc);
     return rc;
 }
+
+/* ======================================================================= */
+/* tfilter_PerfData (src/FilterDefinitions.C:904-1239)                      */
+/* ======================================================================= */
+typedef union { uint64_t u; int64_t i; double d; } perf_t;                 /* perfdata_t */
+
+int32_t orc_filter_perfdata(int op, int type, const int32_t *rank_vals, const uint64_t *rank_counts,
+                            const uint64_t *rank_offs, const void *data_vals,
+                            const uint64_t *data_counts, const uint64_t *data_offs, uint64_t n,
+                            void *out_data, uint64_t out_cap, uint64_t *out_len, int32_t *out_rank)
+{
+    if (type != ORC_UINT64 && type != ORC_INT64 && type != ORC_DOUBLE) return 0;
+    if (op < ORC_SUM || op > ORC_AVG) return 0;
+    perf_t init;
+    memset(&init, op == ORC_MIN ? 0xFF : 0, sizeof init);                  /* :961-965 */
+    perf_t *aggr = NULL;
+    uint64_t sz = 0;
+    unsigned total_nranks = 0;
+    uint64_t data_len = 0;
+    for (uint64_t p = 0; p < n; p++) {                                      /* :984-1113 */
+        data_len = data_counts[p];
+        if (!data_len) continue;
+        int rank = rank_counts[p] ? rank_vals[rank_offs[p]] : 0;
+        int nrank;
+        if (rank < 0) { nrank = -rank; total_nranks += (unsigned)nrank; }   /* :1012-1021 */
+        else          { total_nranks++; nrank = 1; }
+        if (sz < data_len) {                                                /* :1023-1025 */
+            aggr = (perf_t *)realloc(aggr, (size_t)data_len * sizeof *aggr);
+            for (uint64_t u = sz; u < data_len; u++) aggr[u] = init;
+            sz = data_len;
+        }
+        const perf_t *x = (const perf_t *)data_vals + data_offs[p];
+        for (uint64_t u = 0; u < data_len; u++) {
+            perf_t *ag = &aggr[u];
+            switch (op) {
+            case ORC_SUM:                                                   /* sum(), :1027-1045 */
+                if (type == ORC_UINT64) ag->u = ag->u + x[u].u;
+                else if (type == ORC_INT64) ag->i = (int64_t)((uint64_t)ag->i + (uint64_t)x[u].i);
+                else ag->d = ag->d + x[u].d;
+                break;
+            case ORC_MIN:                                                   /* mrn_min(), :1046-1064 */
+                if (type == ORC_UINT64) ag->u = (ag->u < x[u].u) ? ag->u : x[u].u;
+                else if (type == ORC_INT64) ag->i = (ag->i < x[u].i) ? ag->i : x[u].i;
+                else ag->d = (ag->d < x[u].d) ? ag->d : x[u].d;
+                break;
+            case ORC_MAX:                                                   /* mrn_max(), :1065-1083 */
+                if (type == ORC_UINT64) ag->u = (ag->u > x[u].u) ? ag->u : x[u].u;
+                else if (type == ORC_INT64) ag->i = (ag->i > x[u].i) ? ag->i : x[u].i;
+                else ag->d = (ag->d > x[u].d) ? ag->d : x[u].d;
+                break;
+            default:                                                        /* AVG, :1084-1111 */
+                if (type == ORC_UINT64) { uint64_t v = x[u].u; v *= (uint64_t)nrank; ag->u += v; }
+                else if (type == ORC_INT64) {
+                    uint64_t v = (uint64_t)x[u].i * (uint64_t)(int64_t)nrank;
+                    ag->i = (int64_t)((uint64_t)ag->i + v);
+                } else { double v = x[u].d; v *= nrank; ag->d += v; }
+                break;
+            }
+        }
+    }
+    if (data_len && op == ORC_AVG) {                /* the LAST packet's length, :1114-1132 */
+        for (uint64_t u = 0; u < data_len; u++) {
+            if (type == ORC_UINT64) aggr[u].u /= total_nranks;
+            else if (type == ORC_INT64) aggr[u].i /= total_nranks;         /* unsigned -> int64 */
+            else aggr[u].d /= total_nranks;
+        }
+    }
+    int32_t rc = sz <= out_cap;
+    if (rc) {
+        memcpy(out_data, aggr, (size_t)sz * sizeof *aggr);                  /* :1205-1221 */
+        *out_len = sz;
+        *out_rank = 0 - (int)total_nranks;
+    }
+    free(aggr);
+    return rc;
+}

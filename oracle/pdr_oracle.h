@@ -175,6 +175,21 @@ int32_t orc_filter_flat(int op, int type, const void *vals, const int32_t *cnt, 
 int32_t orc_filter_tree(int op, int type, const void *vals, const int32_t *cnt, uint64_t n,
                         const uint32_t *fanin, int nlevels, void *out_val, int32_t *out_cnt);
 
+/* ---- array filters ----------------------------------------------------------------- */
+/*
+ * tfilter_PerfData, aggregations SUM / MIN / MAX / AVG (src/FilterDefinitions.C:904-1239), one
+ * invocation over n packets "%ad %ad %a{uld,ld,lf}" given as columns: rank arrays (int32) and
+ * data arrays of `type` (ORC_UINT64 / ORC_INT64 / ORC_DOUBLE).  Packets without data are skipped.
+ * out_data receives aggr_results (out_len elements, at most out_cap), out_rank the single
+ * element of the output rank array (-total_nranks).  Returns 1, 0 on bad arguments / overflow.
+ * A packet with data but an empty rank array makes the reference dereference NULL; here its
+ * rank reads as 0.
+ */
+int32_t orc_filter_perfdata(int op, int type, const int32_t *rank_vals, const uint64_t *rank_counts,
+                            const uint64_t *rank_offs, const void *data_vals,
+                            const uint64_t *data_counts, const uint64_t *data_offs, uint64_t n,
+                            void *out_data, uint64_t out_cap, uint64_t *out_len, int32_t *out_rank);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,104 @@
+"""tfilter_ArrayConcat and tfilter_PerfData on the device against the oracle's restatement of
+src/FilterDefinitions.C:649-810 and :904-1239.  Integer results and array bytes: bit-exact.
+Doubles: bit-exact too, because the oracle folds in the same order (flat) or over the same
+declared two-level tree.  Parity unpinned by reference artefacts: the reference's tests never
+run these two filters (tests/test_NativeFilters_FE.C covers TFILTER_SUM only)."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O, make_wave, random_values, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+from mrnet_amd import packet as P  # noqa: E402
+
+
+@pytest.mark.parametrize("fmt_s", ["%ad", "%auc", "%alf", "%Ahd", "%as", "%auld"])
+@pytest.mark.parametrize("n", [1, 4, 300])
+def test_array_concat(codec, fmt_s, n):
+    ocols = make_wave(fmt_s, n, seed=n + len(fmt_s), max_count=19)
+    cols = []
+    c = ocols[0]
+    cols.append((c["counts"], c["sub_counts"], c["values"]) if "sub_counts" in c else (c["counts"], c["values"]))
+    wave = P.PacketWave(codec, 77, 101, fmt_s, cols, n)
+    out = P.tfilter_ArrayConcat(wave)
+    assert out is not None and out.n == 1 and out.get_StreamId() == 77 and out.get_Tag() == 101
+    # the reference's output: Packet(stream, tag, fmt, result_array, result_array_size)
+    one = dict(c)
+    total = int(c["offs"][n])
+    one["counts"] = np.array([total], np.uint64)
+    one["offs"] = np.array([0, total], np.uint64)
+    ref, roffs, rlens = O.wave_encode(fmt_s, [one], 1)
+    got = W.Codec.to_numpy(out.wire.arena)[: ref.size]
+    assert int(out.wire.lens[0]) == int(rlens[0]) and np.array_equal(got, ref)
+    assert codec.status() == 0
+    assert P.tfilter_ArrayConcat(P.PacketWave(codec, 1, 1, "%d", [np.arange(3, dtype=np.int32)], 3)) is None
+
+
+def perf_wave(n, t, seed, kmax=8, same_len=False, aggregated=False):
+    dt = np.dtype(O.elem_dtype(t))
+    lens = np.full(n, kmax, np.uint64) if same_len else (splitmix64(seed, n) % np.uint64(kmax + 1)).astype(np.uint64)
+    if dt.kind == "f":
+        vals = ((splitmix64(seed + 1, int(lens.sum())) % np.uint64(2000001)).astype(np.float64) - 1e6) * 1e-3
+    else:
+        vals = random_values(dt, int(lens.sum()), seed + 1)
+        vals = vals >> 3          # sums and the AVG weights still wrap around now and then
+    rcnt = np.ones(n, np.uint64)
+    ranks = np.arange(n, dtype=np.int32)
+    if aggregated:
+        ranks = -((splitmix64(seed + 2, n) % np.uint64(5)).astype(np.int32) + 1)
+        ranks[::3] = np.arange(n, dtype=np.int32)[::3]
+    return (rcnt, ranks), (lens, vals)
+
+
+PERF_FMT = {O.UINT64_T: "%ad %ad %auld", O.INT64_T: "%ad %ad %ald", O.DOUBLE_T: "%ad %ad %alf"}
+
+
+@pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T, O.DOUBLE_T])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG])
+@pytest.mark.parametrize("n,kmax,same,aggr,group", [(1, 8, True, False, 0), (4, 8, False, False, 0),
+                                                     (257, 5, False, True, 0), (1000, 300, False, True, 0),
+                                                     (1000, 8, True, True, 64), (5000, 33, False, True, 256)])
+def test_perfdata(codec, t, op, n, kmax, same, aggr, group):
+    ranks, data = perf_wave(n, t, seed=7 * n + op + t, kmax=kmax, same_len=same, aggregated=aggr)
+    if group:
+        ref = O.filter_perfdata_tree(op, t, ranks, data, [group, 0])
+    else:
+        ref = O.filter_perfdata(op, t, ranks, data)
+    nel = (np.ones(n, np.uint64), data[0].astype(np.int32))
+    wave = P.PacketWave(codec, 5, 100, PERF_FMT[t], [ranks, nel, data], n)
+    out = P.tfilter_PerfData(wave, op, group=group)
+    assert out is not None and out.n == 1
+    cols = out.unpack(PERF_FMT[t])
+    torch.cuda.synchronize()
+    got_rank = W.Codec.to_numpy(cols[0].values).view(np.int32)[:1]
+    got_len = int(W.Codec.to_numpy(cols[2].counts).view(np.uint64)[0])
+    got = W.Codec.to_numpy(cols[2].values).view(O.elem_dtype(t))[:got_len]
+    assert got_len == ref[1].size and int(got_rank[0]) == ref[0]
+    assert int(W.Codec.to_numpy(cols[1].values).view(np.int32)[0]) == got_len
+    assert np.array_equal(got.view(np.uint64), ref[1].view(np.uint64)), (got[:4], ref[1][:4])
+    assert codec.status() == 0
+
+
+def test_perfdata_reference_quirks(codec):
+    """MIN of int64 never exceeds -1, MAX of negative data is 0, a NaN start for double MIN is
+    discarded, packets without data do not count as ranks, AVG divides only the first
+    len(last packet) elements."""
+    t = O.INT64_T
+    ranks = (np.ones(3, np.uint64), np.array([0, 1, 2], np.int32))
+    data = (np.array([2, 0, 1], np.uint64), np.array([5, -7, 9], np.int64))
+    for op, want in ((W.TFILTER_MIN, [-1, -7]), (W.TFILTER_MAX, [9, 0]), (W.TFILTER_SUM, [14, -7]),
+                     (W.TFILTER_AVG, [7, -7])):
+        ref = O.filter_perfdata(op, t, ranks, data)
+        assert ref[0] == -2 and ref[1].tolist() == want, (op, ref)
+        wave = P.PacketWave(codec, 5, 100, PERF_FMT[t], [ranks, (np.ones(3, np.uint64), np.zeros(3, np.int32)), data], 3)
+        cols = P.tfilter_PerfData(wave, op).unpack(PERF_FMT[t])
+        assert W.Codec.to_numpy(cols[2].values).view(np.int64)[:2].tolist() == want
+        assert int(W.Codec.to_numpy(cols[0].values).view(np.int32)[0]) == -2
+    dd = (np.array([1, 1], np.uint64), np.array([3.5, 2.25]))
+    wave = P.PacketWave(codec, 5, 100, PERF_FMT[O.DOUBLE_T], [(np.ones(2, np.uint64), np.array([4, 9], np.int32)),
+                                                            (np.ones(2, np.uint64), np.ones(2, np.int32)), dd], 2)
+    cols = P.tfilter_PerfData(wave, W.TFILTER_MIN).unpack(PERF_FMT[O.DOUBLE_T])
+    assert float(W.Codec.to_numpy(cols[2].values).view(np.float64)[0]) == 2.25

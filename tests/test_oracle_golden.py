@@ -243,3 +243,30 @@ def test_message_framing_round_trip():
     assert O.message_parse(be)[0] == n
     assert O.message_parse(msg[:-1]) is None          # truncated payload
     assert O.message_parse(O.message_build(np.zeros(0, np.uint8), [], [], np.zeros(0, np.uint8), [], []))[0] == 0
+
+
+def test_perfdata_filter_reference_rules():
+    """src/FilterDefinitions.C:904-1239: MIN starts from bytes 0xFF (-1 for int64), MAX / SUM /
+    AVG from 0, packets without data are not ranks, a negative rank is an aggregate of -rank
+    ranks, AVG divides only the first len(last packet) elements.  Unpinned by reference tests."""
+    ranks = (np.ones(3, np.uint64), np.array([0, 1, 2], np.int32))
+    data = (np.array([2, 0, 1], np.uint64), np.array([5, -7, 9], np.int64))
+    want = {O.ORC_SUM if hasattr(O, "ORC_SUM") else 0: [14, -7], 1: [-1, -7], 2: [9, 0], 3: [7, -7]}
+    for op, w in want.items():
+        rank, out = O.filter_perfdata(op, O.INT64_T, ranks, data)
+        assert rank == -2 and out.tolist() == w
+    # aggregates: ranks -3 and -2 weigh 3 and 2 in AVG; total 5
+    ranks = (np.ones(2, np.uint64), np.array([-3, -2], np.int32))
+    data = (np.array([1, 1], np.uint64), np.array([10.0, 20.0]))
+    rank, out = O.filter_perfdata(3, O.DOUBLE_T, ranks, data)
+    assert rank == -5 and out.tolist() == [(10.0 * 3 + 20.0 * 2) / 5]
+    # double MIN: the NaN start is discarded by the first comparison
+    rank, out = O.filter_perfdata(1, O.DOUBLE_T, ranks, data)
+    assert out.tolist() == [10.0]
+    # the same filter at every level of a tree: AVG divides per level
+    ranks = (np.ones(4, np.uint64), np.arange(4, dtype=np.int32))
+    data = (np.full(4, 1, np.uint64), np.array([1, 2, 4, 9], np.uint64))
+    flat = O.filter_perfdata(3, O.UINT64_T, ranks, data)
+    tree = O.filter_perfdata_tree(3, O.UINT64_T, ranks, data, [2, 0])
+    assert flat == (-4, [4]) or (flat[0] == -4 and flat[1].tolist() == [4])       # 16 / 4
+    assert tree[0] == -4 and tree[1].tolist() == [((1 + 2) // 2 * 2 + (4 + 9) // 2 * 2) // 4]   # (2 + 12) / 4 = 3
