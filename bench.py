@@ -222,6 +222,8 @@ def small_wave_extras(codec):
         codec.decode_into(fmt, wire, cols, ok)
         codec.encode_into(fmt, cols, wire)
     out["c2_us_per_wave"] = round(time_call(c2, 200) * 1e6, 2)
+    tg = time_graph(c2, 200)
+    out["c2_us_per_wave_hipgraph"] = None if tg is None else round(tg * 1e6, 2)
     assert int(res[:4].view(torch.int32).item()) == int(vals.sum(dtype=torch.int32).item())
     # config 5 shape: '%lf %d', fused Min / Max / Avg on the wire (one GPU's 131,072-packet shard)
     n5 = 131072
@@ -238,10 +240,34 @@ def small_wave_extras(codec):
             codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
                              n5, 0, W.SHAPE_TREE, r, rok)
     out["c5_shard_us_per_wave"] = round(time_call(c5, 200) * 1e6, 2)
+    out.update(perfdata_extra(codec))
     out.update(mixed_wave_extra(codec))
     assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
     assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
     return out
+
+
+def perfdata_extra(codec):
+    """Config 5, array variant: one GPU's shard of 131,072 '%ad %ad %alf' packets with 8 doubles
+    each (the shape Stream::collect_PerfData emits), element-wise Avg as a two-level tree
+    (nodes of 256 children, then one node over the 512 results)."""
+    n, k = 131072, 8
+    dev = codec.device
+    ranks = W.Column(torch.arange(n, dtype=torch.int32, device=dev), torch.ones(n, dtype=torch.int64, device=dev),
+                     torch.arange(n + 1, dtype=torch.int64, device=dev), n)
+    vals = torch.randn(n * k, dtype=torch.float64, device=dev) * 1e-4 + 1e-3
+    data = W.Column(vals, torch.full((n,), k, dtype=torch.int64, device=dev),
+                    torch.arange(n + 1, dtype=torch.int64, device=dev) * k, n * k)
+    res = {}
+
+    def run():
+        res["o"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, group=256, out_cap=k)
+    t = time_call(run, 50)
+    out, out_len, out_rank = res["o"]
+    assert int(out_len.item()) == k and int(out_rank.item()) == -n
+    want = vals.view(n, k).mean(dim=0)
+    assert torch.allclose(out[:k].view(torch.float64), want, rtol=1e-9)
+    return {"c5b_perfdata_avg_us_per_wave": round(t * 1e6, 1)}
 
 
 def mixed_wave_extra(codec):
@@ -278,8 +304,9 @@ def mixed_wave_extra(codec):
     data = int(lens.sum().item())
     decoded = 20 * n + int(slen.sum()) + int(alen.sum())
     nbytes = 2 * (data + decoded) + 8 * (n + 1)
-    return {"c4_encode_us": round(t_enc * 1e6, 1), "c4_decode_us": round(t_dec * 1e6, 1),
-            "c4_gbps": round(nbytes / (t_enc + t_dec) / 1e9, 1), "c4_wire_mib": round(data / 2**20, 1)}
+    res = {"c4_encode_us": round(t_enc * 1e6, 1), "c4_decode_us": round(t_dec * 1e6, 1),
+           "c4_gbps": round(nbytes / (t_enc + t_dec) / 1e9, 1), "c4_wire_mib": round(data / 2**20, 1)}
+    return res
 
 
 def time_call(fn, reps):
@@ -291,6 +318,33 @@ def time_call(fn, reps):
         fn()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / reps
+
+
+def time_graph(fn, reps):
+    """The same calls captured once in a HIP graph and replayed: what the wave costs on the GPU
+    when the host does not pay a library call per launch (measured: the same time, these waves
+    are bound by the dependent launches on the device, not by the host).  None when capture
+    is refused."""
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                fn()
+        torch.cuda.synchronize()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+    except Exception as e:                                  # noqa: BLE001
+        print("note: graph capture failed: %s" % e, file=sys.stderr)
+        return None
 
 
 def end_to_end(step_obj, reps=5):

@@ -256,32 +256,82 @@ struct PerfOut {
     uint32_t *status;
 };
 
+#define PERF_STAGE_ELEMS 4096        // 32 KB of LDS for the data of one tile of packets
+
+template <int OP, typename T> __device__ __forceinline__ T perf_fold(T acc, T x, int32_t nrank)
+{
+    if (OP == MRPDR_SUM) return acc + x;
+    if (OP == MRPDR_MIN) return (acc < x) ? acc : x;
+    if (OP == MRPDR_MAX) return (acc > x) ? acc : x;
+    return acc + x * (T)nrank;
+}
+
 template <int OP, typename T>
 __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
 {
+    // The packets of the node are taken in tiles of 256: their lengths, offsets and rank counts
+    // go to LDS (one packet per lane), and when the tile's data -- one contiguous run of the
+    // values column -- fits, so does the data, with coalesced loads.  The fold itself is serial
+    // in packet order per element, as the reference's, and then reads LDS only.
+    __shared__ uint64_t s_len[MRPDR_TPB], s_off[MRPDR_TPB];
+    __shared__ int32_t s_nrank[MRPDR_TPB];
+    __shared__ T s_data[PERF_STAGE_ELEMS];
     const uint64_t g = blockIdx.y;
-    const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint32_t t = threadIdx.x;
+    const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + t;
     const uint64_t i0 = g * in.group, i1 = (i0 + in.group < in.n) ? i0 + in.group : in.n;
     const T *data = reinterpret_cast<const T *>(in.data_vals);
     T acc;
     __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
     uint32_t total = 0;
     uint64_t longest = 0, last = 0;
+    for (uint64_t p0 = i0; p0 < i1; p0 += MRPDR_TPB) {
+        const uint32_t np = (uint32_t)((i1 - p0) < MRPDR_TPB ? (i1 - p0) : MRPDR_TPB);
+        __syncthreads();
+        if (t < np) {
+            const uint64_t len = in.data_counts[p0 + t];
+            s_len[t] = len;
+            s_off[t] = in.data_offs[p0 + t];
+            int32_t rank = 0;
+            if (len && in.rank_counts[p0 + t]) rank = in.rank_vals[in.rank_offs[p0 + t]];
+            s_nrank[t] = rank < 0 ? -rank : 1;
+        }
+        __syncthreads();
+        const uint64_t base = s_off[0], run = s_off[np - 1] + s_len[np - 1] - base;
+        // staged only by the workgroup of the first 256 elements: longer arrays read the column
+        // with full wavefronts anyway
+        const bool staged = gridDim.x == 1 && s_off[np - 1] >= base && run <= PERF_STAGE_ELEMS;
+        if (staged) {
+            for (uint64_t k = t; k < run; k += MRPDR_TPB) s_data[k] = data[base + k];
+            __syncthreads();
+        }
+        if (staged) {
+            // branch-free so that the LDS reads of several packets are in flight together; the
+            // fold itself stays in packet order
+#pragma unroll 8
+            for (uint32_t j = 0; j < np; j++) {
+                const uint64_t len = s_len[j];
+                const int32_t nrank = s_nrank[j];
+                const bool active = u < len;
+                const uint64_t k = active ? s_off[j] - base + u : 0;
+                const T x = s_data[k];
+                total += len ? (uint32_t)nrank : 0u;
+                longest = len > longest ? len : longest;
+                const T f = perf_fold<OP, T>(acc, x, nrank);
+                acc = active ? f : acc;
+            }
+            last = s_len[np - 1];
+        } else {
 #pragma unroll 4
-    for (uint64_t i = i0; i < i1; i++) {
-        const uint64_t len = in.data_counts[i];
-        last = len;
-        if (!len) continue;
-        const int32_t rank = in.rank_counts[i] ? in.rank_vals[in.rank_offs[i]] : 0;
-        const int32_t nrank = rank < 0 ? -rank : 1;
-        total += (uint32_t)nrank;
-        if (len > longest) longest = len;
-        if (u < len) {
-            const T x = data[in.data_offs[i] + u];
-            if (OP == MRPDR_SUM) acc = acc + x;
-            else if (OP == MRPDR_MIN) acc = (acc < x) ? acc : x;
-            else if (OP == MRPDR_MAX) acc = (acc > x) ? acc : x;
-            else acc = acc + x * (T)nrank;
+            for (uint32_t j = 0; j < np; j++) {
+                const uint64_t len = s_len[j];
+                last = len;
+                if (!len) continue;
+                const int32_t nrank = s_nrank[j];
+                total += (uint32_t)nrank;
+                if (len > longest) longest = len;
+                if (u < len) acc = perf_fold<OP, T>(acc, data[s_off[j] + u], nrank);
+            }
         }
     }
     if (OP == MRPDR_AVG && last && u < last) {
