@@ -224,28 +224,35 @@ int32_t mrpdr_wave_decode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *
 /* ---- packet headers --------------------------------------------------------
  * Packet::pdr_packet_header (src/Packet.C:557-593) for n packets of one format:
  *   u32 stream_id | i32 tag | u32 src_rank | u32 strlen(fmt)+1 | fmt,NUL |
- *   u64 ndest (= 0) | u8 byteorder
+ *   u64 ndest | ndest x u32 dest_rank | u8 byteorder
  * stream_ids / tags / src_ranks are device columns; a NULL column means the scalar
- * argument applies to every packet.  Header i is written at hdrs + hdr_offsets[i], or at
- * hdrs + i*hdr_stride when hdr_offsets is NULL.
- * mrpdr_header_bytes gives the header length for a format (no destination list). */
+ * argument applies to every packet.  dest_ranks (device, ndest entries, may be NULL with
+ * ndest = 0) is the destination list every packet of the wave carries: upstream waves have
+ * none, a downstream multicast has one list for all its packets (src/Packet.C:579-585).
+ * Header i is written at hdrs + hdr_offsets[i], or at hdrs + i*hdr_stride when hdr_offsets
+ * is NULL.  mrpdr_header_bytes gives the header length without a destination list,
+ * mrpdr_header_bytes_dest with ndest destinations. */
 uint64_t mrpdr_header_bytes(const mrpdr_fmt *f);
+uint64_t mrpdr_header_bytes_dest(const mrpdr_fmt *f, uint64_t ndest);
 int32_t  mrpdr_wave_encode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
                                    uint32_t stream_id, const uint32_t *stream_ids,
                                    int32_t tag, const int32_t *tags,
                                    uint32_t src_rank, const uint32_t *src_ranks,
+                                   const uint32_t *dest_ranks, uint64_t ndest,
                                    uint8_t *hdrs, const uint64_t *hdr_offsets, uint64_t hdr_stride,
                                    void *stream);
 /* Packet::decode_pdr_header (src/Packet.C:87-104): byte order of a header is its own
  * last byte.  Header i is hdrs + hdr_offsets[i] (or i*hdr_stride when hdr_offsets is
  * NULL), hdr_lens[i] long (or hdr_stride when NULL).  Outputs (any may be NULL):
- * stream_ids, tags, src_ranks, byteorders (u8), ndests (u64), and ok[i] = 1 when the
+ * stream_ids, tags, src_ranks, byteorders (u8), ndests (u64), dest_ranks (packet i's first
+ * min(ndest, dest_stride) destinations at dest_ranks + i*dest_stride) and ok[i] = 1 when the
  * header parsed AND its format string equals f's. */
 int32_t  mrpdr_wave_decode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
                                    const uint8_t *hdrs, const uint64_t *hdr_offsets,
                                    const uint64_t *hdr_lens, uint64_t hdr_stride,
                                    uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
-                                   uint8_t *byteorders, uint64_t *ndests, int32_t *ok,
+                                   uint8_t *byteorders, uint64_t *ndests,
+                                   uint32_t *dest_ranks, uint64_t dest_stride, int32_t *ok,
                                    void *stream);
 
 /* ---- message framing -----------------------------------------------------------

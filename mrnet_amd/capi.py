@@ -20,7 +20,7 @@ SYMBOLS = (
     "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
     "mrpdr_wave_sizeof", "mrpdr_wave_encode",
     "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
-    "mrpdr_header_bytes", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
+    "mrpdr_header_bytes", "mrpdr_header_bytes_dest", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
     "mrpdr_wave_filter", "mrpdr_wave_array_concat", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
 )
@@ -79,11 +79,12 @@ def load():
         "mrpdr_wave_decode_finish": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp]),
         "mrpdr_wave_decode": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp, vp]),
         "mrpdr_header_bytes": (u64, [vp]),
-        "mrpdr_wave_encode_headers": (i32, [vp, vp, u64, u32, vp, i32, vp, u32, vp, vp, vp, u64, vp]),
+        "mrpdr_header_bytes_dest": (u64, [vp, u64]),
+        "mrpdr_wave_encode_headers": (i32, [vp, vp, u64, u32, vp, i32, vp, u32, vp, vp, u64, vp, vp, u64, vp]),
         "mrpdr_message_preamble_bytes": (u64, [u64]),
         "mrpdr_message_write_preamble": (i32, [vp, u64, u64, vp, vp, vp]),
         "mrpdr_message_parse_sizes": (i32, [vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64), vp]),
-        "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
+        "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "mrpdr_wave_filter": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
         "mrpdr_wave_array_concat": (i32, [vp, C.POINTER(Column), u64, C.POINTER(Column), vp]),
         "mrpdr_perfdata_scratch_bytes": (u64, [u64, u64, u64]),

@@ -18,6 +18,7 @@ struct HdrEncodeArgs {
     uint32_t stream_id; const uint32_t *stream_ids;
     int32_t  tag;       const int32_t  *tags;
     uint32_t src_rank;  const uint32_t *src_ranks;
+    const uint32_t *dests; uint64_t ndest;          // one destination list for the whole wave
     uint8_t *hdrs; const uint64_t *hdr_offsets; uint64_t hdr_stride; uint64_t n;
 };
 
@@ -32,13 +33,16 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_encode(HdrEncodeArgs a, HdrIm
     st_u<uint32_t>(p + 12, img.fmt_bytes);
     for (uint32_t b = 0; b < img.fmt_bytes; b++) p[16 + b] = img.fmt[b];
     uint8_t *q = p + 16 + img.fmt_bytes;
-    st_u<uint64_t>(q, 0);                       // no destination list
-    q[8] = (uint8_t)MRPDR_LITTLEENDIAN;         // pdrmem_getbo() of this device
+    st_u<uint64_t>(q, a.ndest);                 // pdr_uint64(dest count), src/Packet.C:579-585
+    q += 8;
+    for (uint64_t d = 0; d < a.ndest; d++, q += 4) st_u<uint32_t>(q, a.dests[d]);
+    q[0] = (uint8_t)MRPDR_LITTLEENDIAN;         // pdrmem_getbo() of this device
 }
 
 struct HdrDecodeArgs {
     const uint8_t *hdrs; const uint64_t *hdr_offsets; const uint64_t *hdr_lens; uint64_t hdr_stride;
     uint32_t *stream_ids; int32_t *tags; uint32_t *src_ranks; uint8_t *byteorders; uint64_t *ndests;
+    uint32_t *dests; uint64_t dest_stride;
     int32_t *ok; uint64_t n;
 };
 
@@ -73,7 +77,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_decode(HdrDecodeArgs a, HdrIm
     if (good && space >= 8) {
         nd = ld_wire<8>(p, swap); p += 8; space -= 8;
         if (nd > space / 4) good = false;
-        else { p += nd * 4; space -= nd * 4; }
+        else {
+            if (a.dests)
+                for (uint64_t d = 0; d < nd && d < a.dest_stride; d++)
+                    a.dests[i * a.dest_stride + d] = (uint32_t)ld_wire<4>(p + 4 * d, swap);
+            p += nd * 4; space -= nd * 4;
+        }
     } else good = false;
     if (good && space >= 1) bo = p[0];
     else good = false;

@@ -652,7 +652,13 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
                                             uint64_t n, int32_t sender_bo, mrpdr_column *cols, void *stream)
 {
     if (!check_common("mrpdr_wave_decode_finish", c, f, n)) return 0;
-    if (f->fixed || n == 0) return 1;
+    if (n == 0) {                                   // an empty wave still has sub_offs[0] = 0
+        for (int i = 0; cols && i < f->dev.nf; i++)
+            if (f->dev.f[i].kind == MRPDR_STRING_ARRAY && cols[i].sub_offs)
+                HIP_OK(hipMemsetAsync(cols[i].sub_offs, 0, sizeof(uint64_t), (hipStream_t)stream));
+        return 1;
+    }
+    if (f->fixed) return 1;
     ColsDev cd;
     WireDev wd;
     if (!fill_cols("mrpdr_wave_decode_finish", f, cols, n, true, &cd)) return 0;
@@ -712,20 +718,28 @@ extern "C" uint64_t mrpdr_header_bytes(const mrpdr_fmt *f)
     return f ? 16 + strlen(f->text) + 1 + 8 + 1 : 0;     // src/Packet.C:557-593
 }
 
+extern "C" uint64_t mrpdr_header_bytes_dest(const mrpdr_fmt *f, uint64_t ndest)
+{
+    return f ? mrpdr_header_bytes(f) + 4 * ndest : 0;
+}
+
 extern "C" int32_t mrpdr_wave_encode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n,
                                              uint32_t stream_id, const uint32_t *stream_ids,
                                              int32_t tag, const int32_t *tags,
                                              uint32_t src_rank, const uint32_t *src_ranks,
+                                             const uint32_t *dest_ranks, uint64_t ndest,
                                              uint8_t *hdrs, const uint64_t *hdr_offsets, uint64_t hdr_stride,
                                              void *stream)
 {
     if (!c) return fail("mrpdr_wave_encode_headers: NULL ctx");
     HdrImage img;
     if (!make_image("mrpdr_wave_encode_headers", f, &img)) return 0;
-    if (!hdr_offsets && hdr_stride < mrpdr_header_bytes(f)) return fail("mrpdr_wave_encode_headers: stride shorter than the header");
+    if (ndest && !dest_ranks) return fail("mrpdr_wave_encode_headers: NULL destination list");
+    if (!hdr_offsets && hdr_stride < mrpdr_header_bytes_dest(f, ndest)) return fail("mrpdr_wave_encode_headers: stride shorter than the header");
     if (n == 0) return 1;
     if (!hdrs) return fail("mrpdr_wave_encode_headers: NULL output");
-    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, hdrs, hdr_offsets, hdr_stride, n };
+    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, dest_ranks, ndest,
+                        hdrs, hdr_offsets, hdr_stride, n };
     k_hdr_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
     LAUNCHED("k_hdr_encode");
     return 1;
@@ -735,7 +749,8 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
                                              const uint8_t *hdrs, const uint64_t *hdr_offsets,
                                              const uint64_t *hdr_lens, uint64_t hdr_stride,
                                              uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
-                                             uint8_t *byteorders, uint64_t *ndests, int32_t *ok,
+                                             uint8_t *byteorders, uint64_t *ndests,
+                                             uint32_t *dest_ranks, uint64_t dest_stride, int32_t *ok,
                                              void *stream)
 {
     if (!c) return fail("mrpdr_wave_decode_headers: NULL ctx");
@@ -744,7 +759,7 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
     if (n == 0) return 1;
     if (!hdrs) return fail("mrpdr_wave_decode_headers: NULL input");
     HdrDecodeArgs a = { hdrs, hdr_offsets, hdr_lens, hdr_stride, stream_ids, tags, src_ranks,
-                        byteorders, ndests, ok, n };
+                        byteorders, ndests, dest_ranks, dest_stride, ok, n };
     k_hdr_decode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
     LAUNCHED("k_hdr_decode");
     return 1;

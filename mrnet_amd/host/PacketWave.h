@@ -292,7 +292,7 @@ class PacketWave {
         const uint32_t *src = nullptr;
         if (src_ranks) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
         if (!mrpdr_wave_encode_headers(wc_.ctx, fmt_, n_, stream_id_, nullptr, tag_, nullptr, 0xFFFFFFFFu, src,
-                                       d_hdrs_.ptr<uint8_t>(), nullptr, hdr_len_, wc_.stream)) throw PdrError("mrpdr_wave_encode_headers");
+                                       nullptr, 0, d_hdrs_.ptr<uint8_t>(), nullptr, hdr_len_, wc_.stream)) throw PdrError("mrpdr_wave_encode_headers");
         wc_.sync();
         have_hdrs_ = true;
     }
@@ -303,7 +303,7 @@ class PacketWave {
         d_sid.resize(4 * n_); d_tag.resize(4 * n_); d_src.resize(4 * n_); d_bo.resize(n_); d_ok.resize(4 * n_);
         if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, d_hdrs_.ptr<uint8_t>(), nullptr, nullptr, hdr_len_,
                                        d_sid.ptr<uint32_t>(), d_tag.ptr<int32_t>(), d_src.ptr<uint32_t>(),
-                                       d_bo.ptr<uint8_t>(), nullptr, d_ok.ptr<int32_t>(), wc_.stream))
+                                       d_bo.ptr<uint8_t>(), nullptr, nullptr, 0, d_ok.ptr<int32_t>(), wc_.stream))
             throw PdrError("mrpdr_wave_decode_headers");
         std::vector<uint32_t> sid(n_);
         std::vector<int32_t> tag(n_), okh(n_);

@@ -372,10 +372,12 @@ class Codec:
     # ---- headers ---------------------------------------------------------------------
     def encode_headers(self, fmt, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
                        src_rank=UNKNOWN_RANK, stream_ids=None, tags=None, src_ranks=None,
-                       stride=None, out=None, out_ptr=None, offsets=None):
+                       stride=None, out=None, out_ptr=None, offsets=None, dest_ranks=None):
         """Headers of the wave.  Default: a fresh buffer, header i at i*stride.  With out_ptr
-        (a device address) and offsets, header i goes to out_ptr + offsets[i]."""
-        stride = fmt.header_bytes if stride is None else stride
+        (a device address) and offsets, header i goes to out_ptr + offsets[i].  dest_ranks: the
+        destination list (device int32/uint32 tensor) every packet of a downstream wave carries."""
+        ndest = 0 if dest_ranks is None else dest_ranks.numel()
+        stride = fmt.header_bytes + 4 * ndest if stride is None else stride
         if out_ptr is None:
             hdrs = out if out is not None else torch.zeros(max(n * stride, 1), dtype=torch.uint8,
                                                            device=self.device)
@@ -384,11 +386,15 @@ class Codec:
             hdrs = out
         r = self._lib.mrpdr_wave_encode_headers(self.handle, fmt.handle, n, stream_id, _ptr(stream_ids),
                                                 tag, _ptr(tags), src_rank, _ptr(src_ranks),
+                                                _ptr(dest_ranks), ndest,
                                                 out_ptr, _ptr(offsets), stride, _stream())
         _check(r, "mrpdr_wave_encode_headers")
         return hdrs, stride
 
-    def decode_headers(self, fmt, n, hdrs, stride=0, offsets=None, lens=None):
+    def decode_headers(self, fmt, n, hdrs, stride=0, offsets=None, lens=None, max_dest=0):
+        """Header fields of the wave; with max_dest, also the first max_dest destination ranks of
+        every packet (out['dest_ranks'], n x max_dest)."""
+        dests = self.empty(n * max_dest, torch.int32) if max_dest else None
         out = {
             "stream_id": self.empty(n, torch.int32), "tag": self.empty(n, torch.int32),
             "src_rank": self.empty(n, torch.int32), "byteorder": self.empty(n, torch.uint8),
@@ -398,8 +404,10 @@ class Codec:
                                                 _ptr(lens), stride, _ptr(out["stream_id"]),
                                                 _ptr(out["tag"]), _ptr(out["src_rank"]),
                                                 _ptr(out["byteorder"]), _ptr(out["ndest"]),
-                                                _ptr(out["ok"]), _stream())
+                                                _ptr(dests), max_dest, _ptr(out["ok"]), _stream())
         _check(r, "mrpdr_wave_decode_headers")
+        if max_dest:
+            out["dest_ranks"] = dests.view(n, max_dest)
         return out
 
     # ---- message framing (src/Message.C:48-393) -------------------------------------------

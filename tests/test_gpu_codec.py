@@ -322,12 +322,32 @@ def test_headers_parity(codec):
     lens = np.array([len(x) for x in raw], np.uint64)
     offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     out = codec.decode_headers(fmt, 5, codec.to_device(np.concatenate(raw)),
-                               offsets=codec.to_device(offs), lens=codec.to_device(lens))
+                               offsets=codec.to_device(offs), lens=codec.to_device(lens), max_dest=2)
+    dr = W.Codec.to_numpy(out["dest_ranks"])
+    assert dr[1, 0] == 1 and dr[2].tolist() == [1, 2]          # byte-reversed ranks, made right
     assert W.Codec.to_numpy(out["ok"]).tolist() == [1, 1, 1, 0, 1]
     assert W.Codec.to_numpy(out["stream_id"]).tolist() == [77, 78, 79, 80, 81]
     assert W.Codec.to_numpy(out["tag"]).tolist() == [-3, -4, -5, -6, -7]
     assert W.Codec.to_numpy(out["ndest"]).tolist()[:3] == [0, 1, 2]
     assert W.Codec.to_numpy(out["byteorder"]).tolist() == [1, 1, 1, 0, 1]
+
+
+def test_headers_with_destination_list(codec):
+    """A downstream wave: every header carries the same destination ranks (src/Packet.C:579-585)."""
+    fmt_s = "%d %af"
+    fmt = W.Format(fmt_s)
+    n = 300
+    dest = np.array([3, 9, 4000000000, 7, 11], np.uint32)
+    src = np.arange(n, dtype=np.uint32)
+    hdrs, stride = codec.encode_headers(fmt, n, stream_id=12, tag=-5, src_ranks=codec.to_device(src),
+                                        dest_ranks=codec.to_device(dest))
+    assert stride == len(O.header_encode(12, -5, 0, fmt_s, dest=dest.tolist()))
+    h = W.Codec.to_numpy(hdrs).reshape(n, stride)
+    for i in (0, 1, 255, 256, n - 1):
+        assert h[i].tobytes() == O.header_encode(12, -5, int(src[i]), fmt_s, dest=dest.tolist()).tobytes()
+    out = codec.decode_headers(fmt, n, hdrs, stride=stride, max_dest=8)
+    assert bool(out["ok"].all()) and bool((out["ndest"] == 5).all())
+    assert np.array_equal(W.Codec.to_numpy(out["dest_ranks"]).view(np.uint32)[:, :5], np.tile(dest, (n, 1)))
 
 
 def test_full_size_array_wave_properties(codec):
