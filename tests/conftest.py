@@ -21,6 +21,14 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def frozen():
+    """Vectors frozen from the oracle (tests/golden/make_oracle_vectors.py)."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "oracle_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
 def codec():
     import torch
     if not torch.cuda.is_available():

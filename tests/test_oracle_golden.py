@@ -270,3 +270,25 @@ def test_perfdata_filter_reference_rules():
     tree = O.filter_perfdata_tree(3, O.UINT64_T, ranks, data, [2, 0])
     assert flat == (-4, [4]) or (flat[0] == -4 and flat[1].tolist() == [4])       # 16 / 4
     assert tree[0] == -4 and tree[1].tolist() == [((1 + 2) // 2 * 2 + (4 + 9) // 2 * 2) // 4]   # (2 + 12) / 4 = 3
+
+
+def test_oracle_matches_its_frozen_vectors(frozen, tmp_path):
+    """The committed vectors are what the oracle produces today (a change of the oracle's
+    behaviour must show up as a diff of tests/golden/oracle_vectors.json)."""
+    import json
+    import subprocess
+    import sys
+    import os
+    import shutil
+    here = os.path.dirname(os.path.abspath(__file__))
+    gen = os.path.join(here, "golden", "make_oracle_vectors.py")
+    path = os.path.join(here, "golden", "oracle_vectors.json")
+    keep = tmp_path / "kept.json"
+    shutil.copy(path, keep)
+    try:
+        subprocess.check_call([sys.executable, gen])
+        with open(path) as f:
+            again = json.load(f)
+    finally:
+        shutil.copy(keep, path)
+    assert again == frozen
