@@ -59,7 +59,12 @@ enum mrpdr_byteorder { MRPDR_LITTLEENDIAN = 0, MRPDR_BIGENDIAN = 1 };
 enum mrpdr_kind { MRPDR_SCALAR = 0, MRPDR_ARRAY = 1, MRPDR_STRING = 2, MRPDR_STRING_ARRAY = 3 };
 
 /* filter operators: TFILTER_SUM / MIN / MAX / AVG (src/FilterDefinitions.C:90-645) */
-enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 3 };
+enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 3,
+                       /* bitwise OR of integer values: the BitsetOr filter and the bit field of
+                        * IntegerPercentiles (Examples/FaultRecovery/FaultRecoveryFilter.C:29-132) */
+                       MRPDR_OR = 4,
+                       /* bitwise AND (std::bitset<N> keeps N bits: AND with the mask) */
+                       MRPDR_AND = 5 };
 
 /*
  * Shape of the reduction a filter call applies to a wave.

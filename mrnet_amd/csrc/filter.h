@@ -49,6 +49,19 @@ template <> __device__ inline float    div_cnt<float>(float v, int32_t n)       
 template <> __device__ inline double   mul_cnt<double>(double v, int32_t n)     { return v * (double)n; }
 template <> __device__ inline double   div_cnt<double>(double v, int32_t n)     { return v / (double)n; }
 
+// aggr_val |= cval (Examples/FaultRecovery/FaultRecoveryFilter.C:112-122); the host admits
+// integer types only
+template <bool AND, typename T> __device__ inline T or_bits(T a, T b)
+{
+    uint64_t x = 0, y = 0;
+    __builtin_memcpy(&x, &a, sizeof(T));
+    __builtin_memcpy(&y, &b, sizeof(T));
+    x = AND ? (x & y) : (x | y);
+    T r;
+    __builtin_memcpy(&r, &x, sizeof(T));
+    return r;
+}
+
 template <int OP, typename T> struct Folder {
     T res;
     int32_t cnt;
@@ -62,6 +75,10 @@ template <int OP, typename T> struct Folder {
             res = any ? ((res > x) ? res : x) : x;
         } else if (OP == MRPDR_MIN) {
             res = any ? ((res < x) ? res : x) : x;
+        } else if (OP == MRPDR_OR) {
+            res = or_bits<false>(res, x);
+        } else if (OP == MRPDR_AND) {
+            res = any ? or_bits<true>(res, x) : x;
         } else {
             res = (T)(res + mul_cnt<T>(x, c));
             cnt += c;

@@ -836,6 +836,8 @@ static int32_t run_filter_op(mrpdr_ctx *c, int32_t op, int32_t shape, const Filt
     case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(c, shape, in, result, result_ok, st);
     case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(c, shape, in, result, result_ok, st);
     case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_OR:  return run_filter<MRPDR_OR, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_AND: return run_filter<MRPDR_AND, T>(c, shape, in, result, result_ok, st);
     }
     return fail("mrpdr_wave_filter: unknown operator %d", op);
 }
@@ -852,6 +854,8 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     if (n && !values) return fail("mrpdr_wave_filter: NULL values");
     if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
     if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
+    if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
+        return fail("mrpdr_wave_filter: bitwise operators need an integer type");
     FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
     uint8_t *res = (uint8_t *)result;
     hipStream_t st = (hipStream_t)stream;

@@ -234,3 +234,59 @@ def tfilter_PerfData(ipackets, aggr_id, group=0):
     out_cols = [W.Column(out_rank, one, offs1, 1), W.Column(nelems, one, offs1, 1),
                 W.Column(data, out_len, doffs, data.numel())]
     return _from_columns(ipackets, fmt, out_cols)
+
+
+def BitsetOr(ipackets, shape=W.SHAPE_TREE):
+    """Examples/FaultRecovery/FaultRecoveryFilter.C:107-128: one '%uld' packet, the OR of all inputs."""
+    if ipackets.fmt.text != "%uld":
+        return None
+    return _run_filter(W.FILTER_OR, ipackets, shape)
+
+
+def IntegerPercentiles(ipackets, state=None, shape=W.SHAPE_TREE):
+    """Examples/FaultRecovery/FaultRecoveryFilter.C:29-86 for waves of '%uld %ud %ud' packets
+    (bit set, max, min): OR of the bit sets, maximum of the maxima, minimum of the minima, folded
+    into the filter state the reference keeps in `void **filter_state`.  `state` is that state as
+    a 16-byte device tensor in the packet's own layout (None = a fresh one: bits 0, max 0,
+    min fr_range_max); returns (output PacketWave, new state).  Integer OR / max / min do not
+    depend on the order, so the state simply is one more input of each fold."""
+    codec, fmt, n = ipackets.codec, ipackets.fmt, ipackets.n
+    if fmt.text != "%uld %ud %ud" or n == 0 or ipackets.has_Error() or ipackets.wire.offsets is not None:
+        return None, state
+    if state is None:
+        state = torch.zeros(16, dtype=torch.uint8, device=codec.device)
+        state[12:16] = torch.tensor(list((FR_RANGE_MAX).to_bytes(4, "little")), dtype=torch.uint8,
+                                    device=codec.device)
+    mask = torch.tensor(list(((1 << FR_BINS) - 1).to_bytes(8, "little")), dtype=torch.uint8, device=codec.device)
+    # state and wave side by side: packet 0 is the state
+    rows = torch.cat([state, ipackets.wire.arena[: n * 16]])
+    base, swap = rows.data_ptr(), 0
+    if ipackets.byteorder != W.LITTLEENDIAN:        # the state is native: fold the wave, then the state
+        swap = 1
+    out = torch.zeros(16, dtype=torch.uint8, device=codec.device)
+    ok = torch.zeros(1, dtype=torch.int32, device=codec.device)
+    for op, dt, off, w in ((W.FILTER_OR, W.DataType.UINT64_T, 0, 8), (W.TFILTER_MAX, W.DataType.UINT32_T, 8, 4),
+                           (W.TFILTER_MIN, W.DataType.UINT32_T, 12, 4)):
+        if swap:
+            part, _ = codec.filter_raw(op, dt, base + 16 + off, 16, None, 0, n, 1, shape)
+            pair = torch.cat([state[off:off + w], part[:w]])
+            res, _ = codec.filter_raw(op, dt, pair.data_ptr(), w, None, 0, 2, 0, W.SHAPE_FLAT)
+        else:
+            res, _ = codec.filter_raw(op, dt, base + off, 16, None, 0, n + 1, 0, shape)
+        if op == W.FILTER_OR:                       # fr_bin_set keeps fr_bins bits
+            pair = torch.cat([res[:8], mask])
+            res, _ = codec.filter_raw(W.FILTER_AND, dt, pair.data_ptr(), 8, None, 0, 2, 0, W.SHAPE_FLAT)
+        out[off:off + w] = res[:w]
+    opk = PacketWave.__new__(PacketWave)
+    opk.codec, opk.fmt, opk.n = codec, fmt, 1
+    opk.stream_id, opk.tag = ipackets.get_StreamId(), PROT_WAVE
+    opk.src_rank, opk.src_ranks, opk.inlet_rank = W.UNKNOWN_RANK, None, W.UNKNOWN_RANK
+    opk._hdrs, opk._error, opk.byteorder = None, False, W.LITTLEENDIAN
+    opk.wire = W.WireWave(out, 1, None, None, 16)
+    opk.columns, opk.ok, opk._decoded = None, None, False
+    opk.result_ok = ok
+    return opk, out.clone()
+
+
+FR_RANGE_MAX, FR_BINS = 1000, 20      # Examples/FaultRecovery/FaultRecovery.h:12-13
+PROT_WAVE = 102                       # FirstApplicationTag + 2 in that example's protocol enum (:17-19)

@@ -60,6 +60,7 @@ class DataType(enum.IntEnum):
 LITTLEENDIAN, BIGENDIAN = 0, 1
 SCALAR, ARRAY, STRING, STRING_ARRAY = 0, 1, 2, 3
 TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3      # operator codes of the C ABI
+FILTER_OR, FILTER_AND = 4, 5      # bitwise (not built-in TFILTER_*: the BitsetOr / IntegerPercentiles examples)
 SHAPE_FLAT, SHAPE_TREE = 0, 1
 TREE_FANINS = (4, 2, 2, 2, 2, 2, 2, 4, 0)
 

@@ -26,7 +26,7 @@ _LIB_PATH = os.path.join(_HERE, "libpdr_oracle.so")
  INT16_LRG_ARRAY_T, UINT16_LRG_ARRAY_T, INT32_LRG_ARRAY_T, UINT32_LRG_ARRAY_T,
  INT64_LRG_ARRAY_T, UINT64_LRG_ARRAY_T, FLOAT_LRG_ARRAY_T, DOUBLE_LRG_ARRAY_T) = range(34)
 
-SUM, MIN, MAX, AVG = 0, 1, 2, 3
+SUM, MIN, MAX, AVG, OR, AND = 0, 1, 2, 3, 4, 5
 LITTLE, BIG = 0, 1
 
 _ELEM_DTYPE = {

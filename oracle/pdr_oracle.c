@@ -845,6 +845,27 @@ static int32_t fold_once(int op, int type, const acc_t *v, const int32_t *cnt, u
         *out_cnt = nres;
         break;
     }
+    case ORC_OR:                                 /* aggr_val |= cval, Examples/FaultRecovery/FaultRecoveryFilter.C:112-122 */
+        if (type == ORC_FLOAT || type == ORC_DOUBLE) return 0;
+        for (uint64_t i = 0; i < m; i++) {
+            uint64_t a = 0, b = 0;
+            memcpy(&a, &res, (size_t)orc_type_width(type));
+            memcpy(&b, &v[i], (size_t)orc_type_width(type));
+            a |= b;
+            memcpy(&res, &a, (size_t)orc_type_width(type));
+        }
+        break;
+    case ORC_AND:                                /* std::bitset<N>(v): v & mask */
+        if (type == ORC_FLOAT || type == ORC_DOUBLE) return 0;
+        res = v[0];
+        for (uint64_t i = 1; i < m; i++) {
+            uint64_t a = 0, b = 0;
+            memcpy(&a, &res, (size_t)orc_type_width(type));
+            memcpy(&b, &v[i], (size_t)orc_type_width(type));
+            a &= b;
+            memcpy(&res, &a, (size_t)orc_type_width(type));
+        }
+        break;
     default:
         return 0;
     }

@@ -159,7 +159,8 @@ int32_t orc_message_parse(const char *msg, uint64_t msg_len, uint32_t *n, uint64
                           uint64_t *hdr_lens, uint64_t *buf_offs, uint64_t *buf_lens, uint32_t cap_n);
 
 /* ---- filters (src/FilterDefinitions.C:90-645, 1925-2136) ---------------- */
-enum orc_filter_op { ORC_SUM = 0, ORC_MIN = 1, ORC_MAX = 2, ORC_AVG = 3 };
+enum orc_filter_op { ORC_SUM = 0, ORC_MIN = 1, ORC_MAX = 2, ORC_AVG = 3,
+                     ORC_OR = 4 /* bitwise, integer types: the BitsetOr example filter */, ORC_AND = 5 };
 /*
  * Flat left fold over n values of scalar `type` (cnt != NULL only for AVG).
  * out_val receives the result in the element type, out_cnt the summed count (AVG).

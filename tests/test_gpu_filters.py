@@ -204,3 +204,42 @@ def test_sharded_wave_combine(codec, opname, op):
         whole = O.filter_tree(op, O.DOUBLE_T, v, c, W.TREE_FANINS)
         last = O.filter_flat(op, O.DOUBLE_T, np.array([whole[0]]), np.array([whole[1]], np.int32))
         assert np.asarray(W.result_value(res1, ok1, np.dtype(np.float64), op)[0]).tobytes() == np.asarray(last[0]).tobytes()
+
+
+def test_bitwise_or_and_integer_percentiles(codec):
+    """The reducers of Examples/FaultRecovery/FaultRecoveryFilter.C: BitsetOr over '%uld', and
+    IntegerPercentiles over '%uld %ud %ud' (bits | max | min) with its persistent state.
+    Unpinned by reference artefacts; the oracle restates the loops."""
+    from mrnet_amd import packet as P
+    n = 5000
+    bits = splitmix64(71, n) & splitmix64(72, n) & splitmix64(73, n)
+    wave = P.PacketWave(codec, 9, 100, "%uld", [bits], n)
+    for shape in (W.SHAPE_FLAT, W.SHAPE_TREE):
+        out = P.BitsetOr(wave, shape)
+        want = O.filter_flat(O.OR, O.UINT64_T, bits, None)[0]
+        assert int(W.Codec.to_numpy(out.wire.arena)[:8].view(np.uint64)[0]) == int(want) == int(np.bitwise_or.reduce(bits))
+    for t, dt in ((O.INT16_T, np.int16), (O.UCHAR_T, np.uint8), (O.INT32_T, np.int32)):
+        v = random_values(dt, 777, 5)
+        res, ok = codec.filter_columns(W.FILTER_OR, t, codec.to_device(v), None, W.SHAPE_TREE)
+        assert W.Codec.to_numpy(res)[: np.dtype(dt).itemsize].tobytes() == np.asarray(O.filter_flat(O.OR, t, v, None)[0]).tobytes()
+        res, ok = codec.filter_columns(W.FILTER_AND, t, codec.to_device(v | dt(0x11)), None, W.SHAPE_TREE)
+        assert W.Codec.to_numpy(res)[: np.dtype(dt).itemsize].tobytes() == \
+            np.asarray(O.filter_flat(O.AND, t, v | dt(0x11), None)[0]).tobytes()
+    with pytest.raises(W.PdrError):
+        codec.filter_columns(W.FILTER_OR, O.DOUBLE_T, codec.to_device(np.zeros(4)), None)
+    # IntegerPercentiles: two waves through the same state
+    state = None
+    smin, smax, sbits = P.FR_RANGE_MAX, 0, 0
+    for seed in (1, 2):
+        m = 3000
+        b = (splitmix64(seed, m) >> np.uint64(40)).astype(np.uint64)
+        mx = (splitmix64(seed + 10, m) % np.uint64(1000)).astype(np.uint32)
+        mn = (mx // np.uint32(2)).astype(np.uint32)
+        w = P.PacketWave(codec, 9, P.PROT_WAVE, "%uld %ud %ud", [b, mx, mn], m)
+        out, state = P.IntegerPercentiles(w, state)
+        sbits |= int(np.bitwise_or.reduce(b)) & ((1 << P.FR_BINS) - 1)
+        smax, smin = max(smax, int(mx.max())), min(smin, int(mn.min()))
+        raw = W.Codec.to_numpy(out.wire.arena)
+        assert (int(raw[:8].view(np.uint64)[0]), int(raw[8:12].view(np.uint32)[0]), int(raw[12:16].view(np.uint32)[0])) \
+            == (sbits, smax, smin)
+        assert out.get_Tag() == P.PROT_WAVE
