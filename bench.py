@@ -242,9 +242,35 @@ def small_wave_extras(codec):
     out["c5_shard_us_per_wave"] = round(time_call(c5, 200) * 1e6, 2)
     out.update(perfdata_extra(codec))
     out.update(mixed_wave_extra(codec))
+    out.update(batched_small_waves_extra(dev))
     assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
     assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
     return out
+
+
+def batched_small_waves_extra(dev):
+    """Config 2 again, 64 waves per launch: 64 x 65,536 '%d' packets decoded from a big-endian
+    sender and re-encoded by one call each -- the only way a 256 KiB wave can be measured
+    against the memory system instead of against launch latency."""
+    waves, n1 = 64, 65536
+    n = waves * n1
+    codec = W.Codec(device=dev.index, max_packets=n)
+    fmt = W.Format("%d")
+    vals = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device=dev)
+    wire = W.WireWave(vals.view(torch.uint8).clone(), n, None, None, 4)
+    out_wire = W.WireWave(torch.empty(4 * n, dtype=torch.uint8, device=dev), n, None, None, 4)
+    cols = codec.alloc_columns(fmt, n)
+    ok = torch.empty(n, dtype=torch.int32, device=dev)
+
+    def step():
+        codec.decode_into(fmt, wire, cols, ok, W.BIGENDIAN)
+        codec.encode_into(fmt, cols, out_wire)
+    t = time_call(step, 50)
+    want = vals.view(torch.uint8).view(n, 4).flip(-1).contiguous().view(torch.int32).view(-1)
+    assert torch.equal(cols[0].values.view(torch.int32), want) and bool(ok.all())
+    assert torch.equal(out_wire.arena.view(torch.int32), want)
+    nbytes = 4 * 4 * n + 4 * n                        # wire + column, both ways, + ok flags
+    return {"c2_x64_us_per_launch_pair": round(t * 1e6, 1), "c2_x64_gbps": round(nbytes / t / 1e9, 1)}
 
 
 def perfdata_extra(codec):

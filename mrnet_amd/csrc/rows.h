@@ -63,9 +63,18 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode(FmtDev fmt, WireDev w
         uint64_t v = 0;
         // same test as every pdrmem_get*: width > remaining space -> FALSE
         if (good && (uint64_t)at + w <= len && at + w <= stride) {
-            for (uint32_t b = 0; b < w; b++) {
-                const uint32_t src = SWAP ? (w - 1 - b) : b;      // src/byte_order.c:12-16
-                v |= (uint64_t)row[at + src] << (8 * b);
+            if (((at | stride) & (w - 1)) == 0) {                 // naturally aligned in the LDS tile
+                switch (w) {
+                case 1: v = row[at]; break;
+                case 2: v = *reinterpret_cast<const uint16_t *>(row + at); if (SWAP) v = __builtin_bswap16((uint16_t)v); break;
+                case 4: v = *reinterpret_cast<const uint32_t *>(row + at); if (SWAP) v = __builtin_bswap32((uint32_t)v); break;
+                default: v = *reinterpret_cast<const uint64_t *>(row + at); if (SWAP) v = __builtin_bswap64(v); break;
+                }
+            } else {
+                for (uint32_t b = 0; b < w; b++) {
+                    const uint32_t src = SWAP ? (w - 1 - b) : b;  // src/byte_order.c:12-16
+                    v |= (uint64_t)row[at + src] << (8 * b);
+                }
             }
         } else {
             good = false;
@@ -88,7 +97,16 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev w
         for (int f = 0; f < fmt.nf; f++) {
             const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
             const uint64_t v = ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + i * w, (int)w, false);
-            for (uint32_t b = 0; b < w; b++) row[at + b] = (uint8_t)(v >> (8 * b));
+            if (((at | stride) & (w - 1)) == 0) {
+                switch (w) {
+                case 1: row[at] = (uint8_t)v; break;
+                case 2: *reinterpret_cast<uint16_t *>(row + at) = (uint16_t)v; break;
+                case 4: *reinterpret_cast<uint32_t *>(row + at) = (uint32_t)v; break;
+                default: *reinterpret_cast<uint64_t *>(row + at) = v; break;
+                }
+            } else {
+                for (uint32_t b = 0; b < w; b++) row[at + b] = (uint8_t)(v >> (8 * b));
+            }
         }
         for (uint32_t b = fmt.fixed_bytes; b < stride; b++) row[b] = 0;     // arena padding
     }
