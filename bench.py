@@ -47,6 +47,10 @@ def parse():
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL) for the real run; gloo to rehearse "
                                                      "several ranks on one GPU")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    p.add_argument("--overlap", action="store_true",
+                   help="run the encode side's sizing, prefixes and plan on a second stream under the decode "
+                        "payload kernel (measured: no gain -- the payload kernel fills the machine and the "
+                        "event hand-offs cost what the hidden kernels save; default: one stream)")
     return p.parse_args()
 
 
@@ -70,9 +74,15 @@ def make_be_wave(n, m, seed, device):
 class ArrayWaveStep:
     """Preallocated decode -> sizeof -> encode of one '%af' wave."""
 
-    def __init__(self, codec, n, m, seed):
+    def __init__(self, codec, n, m, seed, overlap=False):
         self.codec, self.n, self.m = codec, n, m
         dev = codec.device
+        # the encode side has its own context (workspace) so that its preparation can run on a
+        # second stream while the decode payload kernel streams
+        self.overlap = overlap
+        self.enc = W.Codec(device=dev.index, max_packets=codec.max_packets) if overlap else codec
+        self.side = torch.cuda.Stream(device=dev, priority=-1) if overlap else None
+        self.ev_counts, self.ev_prepared = torch.cuda.Event(), torch.cuda.Event()
         self.fmt = W.Format("%af")
         self.src = make_be_wave(n, m, seed, dev)
         self.cols = [W.Column(torch.empty(n * m, dtype=torch.int32, device=dev),
@@ -101,15 +111,31 @@ class ArrayWaveStep:
     def decode_payload(self):
         self.codec.decode_finish(self.fmt, self.src, self.cols, W.BIGENDIAN)
 
+    def encode_prepare(self):
+        self.enc.sizeof(self.fmt, self.cols, self.n, self.align, self.phase, want_total=False,
+                        lens=self.out_lens, offsets=self.out_offs)
+        self.enc.encode_begin(self.fmt, self.cols, self.dst)
+
     def encode(self):
-        self.codec.sizeof(self.fmt, self.cols, self.n, self.align, self.phase, want_total=False,
-                          lens=self.out_lens, offsets=self.out_offs)
-        self.codec.encode_into(self.fmt, self.cols, self.dst)
+        self.encode_prepare()
+        self.enc.encode_finish(self.fmt, self.cols, self.dst)
 
     def step(self):
-        self.decode()
-        self.decode_payload()
-        self.encode()
+        if not self.overlap:
+            self.decode()
+            self.decode_payload()
+            self.encode()
+            return
+        main = torch.cuda.current_stream()
+        self.decode()                                   # counts, offsets, scalars
+        self.ev_counts.record(main)
+        with torch.cuda.stream(self.side):              # needs only what decode() left
+            self.side.wait_event(self.ev_counts)
+            self.encode_prepare()
+            self.ev_prepared.record(self.side)
+        self.decode_payload()                           # meanwhile: the decode payload stream
+        main.wait_event(self.ev_prepared)
+        self.enc.encode_finish(self.fmt, self.cols, self.dst)
 
     def verify(self):
         """decode(BE) is the byte reversal of the wire; encode gives the LE wire of the same values."""
@@ -412,7 +438,7 @@ def main():
         print("note: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
 
     codec = W.Codec(device=local, max_packets=max(a.packets, 1 << 18))
-    st = ArrayWaveStep(codec, a.packets, a.elems, seed=3 + rank)
+    st = ArrayWaveStep(codec, a.packets, a.elems, seed=3 + rank, overlap=a.overlap)
 
     def barrier():
         torch.cuda.synchronize()
@@ -430,6 +456,8 @@ def main():
     # with HIP events on the stream it launches on (mrpdr_ctx_perf_*), which gives the
     # per-launch duration of the dominant kernel from inside this same region.
     codec.perf_enable(os.environ.get('MRPDR_BENCH_NO_PERF') is None)
+    if st.enc is not codec:
+        st.enc.perf_enable(os.environ.get('MRPDR_BENCH_NO_PERF') is None)
     barrier()
     t0 = time.perf_counter()
     for k in range(a.steps):
@@ -438,6 +466,9 @@ def main():
     dt = time.perf_counter() - t0
     perf = codec.perf_collect()
     codec.perf_enable(False)
+    if st.enc is not codec:
+        perf["encode"] = st.enc.perf_collect()["encode"]
+        st.enc.perf_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if a.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -470,6 +501,7 @@ def main():
                                    "decode -> sizeof -> encode little-endian, device-resident"
                                    % (a.packets, a.elems),
                        "packets_per_gpu": a.packets, "elems_per_packet": a.elems,
+                       "streams": 2 if a.overlap else 1,
                        "algorithmic_bytes_per_step_per_gpu": st.bytes_step,
                        "pct_of_hbm_peak": round(100.0 * value / world / HBM_PEAK_GBPS, 2)},
             "roofline": {"bound": "hbm", "kernel": "k_copy<4,swap,decode>",

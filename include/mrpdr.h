@@ -201,6 +201,15 @@ int32_t mrpdr_wave_sizeof(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column
  * Padding bytes of a packed fixed layout (stride > length) are written as zero. */
 int32_t mrpdr_wave_encode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
                           uint64_t n, const mrpdr_wire *wire, void *stream);
+/* The same in two calls, for callers that overlap work on two streams: begin writes scalars
+ * and length prefixes and plans the payload streams -- it reads only counts / offs and the
+ * scalar columns, so it may run while the array values are still being produced (e.g. by
+ * mrpdr_wave_decode_finish of ANOTHER ctx on another stream); finish moves the payloads.
+ * finish must follow begin on the same ctx with the same arguments. */
+int32_t mrpdr_wave_encode_begin(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                uint64_t n, const mrpdr_wire *wire, void *stream);
+int32_t mrpdr_wave_encode_finish(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                 uint64_t n, const mrpdr_wire *wire, void *stream);
 
 /* ---- decode: Packet::decode_pdr_data for a whole wave -------------------------
  * (src/Packet.C:106-133 -> pdr_packet_data DECODE -> pdrmem_get* / pdrmem_get*_swap,

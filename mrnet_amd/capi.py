@@ -18,7 +18,7 @@ SYMBOLS = (
     "mrpdr_fmt_compile", "mrpdr_fmt_free", "mrpdr_fmt_nfields", "mrpdr_fmt_field_type",
     "mrpdr_fmt_field_kind", "mrpdr_fmt_field_width", "mrpdr_fmt_is_fixed",
     "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
-    "mrpdr_wave_sizeof", "mrpdr_wave_encode",
+    "mrpdr_wave_sizeof", "mrpdr_wave_encode", "mrpdr_wave_encode_begin", "mrpdr_wave_encode_finish",
     "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
     "mrpdr_header_bytes", "mrpdr_header_bytes_dest", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
@@ -74,6 +74,8 @@ def load():
         "mrpdr_fmt_string": (C.c_char_p, [vp]),
         "mrpdr_wave_sizeof": (i32, [vp, vp, C.POINTER(Column), u64, u32, u32, vp, vp, C.POINTER(u64), vp]),
         "mrpdr_wave_encode": (i32, [vp, vp, C.POINTER(Column), u64, C.POINTER(Wire), vp]),
+        "mrpdr_wave_encode_begin": (i32, [vp, vp, C.POINTER(Column), u64, C.POINTER(Wire), vp]),
+        "mrpdr_wave_encode_finish": (i32, [vp, vp, C.POINTER(Column), u64, C.POINTER(Wire), vp]),
         "mrpdr_wave_decode_begin": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp,
                                           C.POINTER(u64), vp]),
         "mrpdr_wave_decode_finish": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp]),

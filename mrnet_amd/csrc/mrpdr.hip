@@ -196,6 +196,12 @@ struct mrpdr_ctx {
     uint64_t *sa_bytes;       // per-field byte totals of string arrays (accumulated by the walk)
     uint64_t *pkt_bytes;      // string arrays: string bytes per packet, and their scan
     uint64_t *pkt_boffs;
+    // chunk plans left by mrpdr_wave_encode_begin for mrpdr_wave_encode_finish
+    struct {
+        const mrpdr_fmt *fmt; uint64_t n; const uint8_t *wire_base;
+        uint32_t used;                      // descriptors taken
+        uint32_t off[MRPDR_MAXF], nd[MRPDR_MAXF];   // per field: where its plan starts, how long (0 = none)
+    } plan;
     uint64_t *tile_cnt;       // tile kernels: element totals per (variable field, tile)
     uint64_t  ntile_cnt;      // tiles the workspace holds per field
     ChunkDesc *desc;          // chunk descriptors of the payload kernels
@@ -487,13 +493,40 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
 // ---------------------------------------------------------------------------
 // segment copies
 // ---------------------------------------------------------------------------
+enum { COPY_BOTH = 0, COPY_PLAN = 1, COPY_RUN = 2 };   // plan + copy; plan only (encode_begin); copy a planned field
+
 template <int W, bool SWAP, bool ENCODE>
-static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const ColsDev &cd, hipStream_t st)
+static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const ColsDev &cd, hipStream_t st,
+                           int mode = COPY_BOTH)
 {
     // upper bound of the payload: it cannot exceed the arena or the column
     const uint64_t bound = a.wire.bytes < a.dense_cap ? a.wire.bytes : a.dense_cap;
+    const uint64_t nchunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
+    const bool by_packet = bound / a.n < 2048;
+    if (mode == COPY_PLAN) {
+        // the plan of this field behind the plans already taken, when it fits the descriptor buffer
+        if (by_packet || nchunks > DESC_CAP - c->plan.used) return 1;
+        a.first_chunk = 0;
+        k_copy_plan<ENCODE><<<blocks_for(nchunks, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc + c->plan.used, nchunks);
+        LAUNCHED("k_copy_plan");
+        c->plan.off[a.field] = c->plan.used;
+        c->plan.nd[a.field] = (uint32_t)nchunks;
+        c->plan.used += (uint32_t)nchunks;
+        return 1;
+    }
+    if (mode == COPY_RUN && c->plan.nd[a.field]) {
+        const uint32_t nd = c->plan.nd[a.field];
+        bool timed;
+        if (!perf_begin(c, st, &timed)) return 0;
+        a.first_chunk = 0;
+        CopyFast fa = { c->desc + c->plan.off[a.field], a.wire.base, a.dense };
+        if (bound >= (32ull << 20)) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
+        else                        k_copy<W, SWAP, ENCODE, false><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
+        LAUNCHED("k_copy");
+        return perf_end(c, st, timed, ENCODE ? 1 : 0);
+    }
     // short payloads (under 2 KiB per packet on average): 16 lanes per packet
-    if (bound / a.n < 2048) {
+    if (by_packet) {
         const uint64_t threads = a.n * PKT_LANES;
         const bool timed = c->perf_on && c->perf_used < PERF_SLOTS;
         if (timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
@@ -505,7 +538,7 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
         }
         return 1;
     }
-    const uint64_t chunks = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
+    const uint64_t chunks = nchunks;
     // data this large is touched once per kernel: keep it out of the caches
     const bool nt = bound >= (32ull << 20);
     for (uint64_t first = 0; first < chunks; first += DESC_CAP) {
@@ -529,7 +562,7 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
 
 template <bool ENCODE>
 static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
-                          uint64_t n, bool swap, hipStream_t st)
+                          uint64_t n, bool swap, hipStream_t st, int mode = COPY_BOTH)
 {
     const FieldDev &fd = f->dev.f[field];
     CopyArgs a;
@@ -545,49 +578,83 @@ static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, c
     // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
     const bool sw = swap && fd.width > 1 && !ENCODE;
     switch (fd.width) {
-    case 1: return launch_copy<1, false, ENCODE>(c, a, f->dev, cd, st);
-    case 2: return sw ? launch_copy<2, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<2, false, ENCODE>(c, a, f->dev, cd, st);
-    case 4: return sw ? launch_copy<4, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<4, false, ENCODE>(c, a, f->dev, cd, st);
-    default: return sw ? launch_copy<8, true, ENCODE>(c, a, f->dev, cd, st) : launch_copy<8, false, ENCODE>(c, a, f->dev, cd, st);
+    case 1: return launch_copy<1, false, ENCODE>(c, a, f->dev, cd, st, mode);
+    case 2: return sw ? launch_copy<2, true, ENCODE>(c, a, f->dev, cd, st, mode) : launch_copy<2, false, ENCODE>(c, a, f->dev, cd, st, mode);
+    case 4: return sw ? launch_copy<4, true, ENCODE>(c, a, f->dev, cd, st, mode) : launch_copy<4, false, ENCODE>(c, a, f->dev, cd, st, mode);
+    default: return sw ? launch_copy<8, true, ENCODE>(c, a, f->dev, cd, st, mode) : launch_copy<8, false, ENCODE>(c, a, f->dev, cd, st, mode);
     }
 }
 
 // ---------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------
-extern "C" int32_t mrpdr_wave_encode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
-                                     uint64_t n, const mrpdr_wire *wire, void *stream)
+// phase 1 = begin (everything but the payload streams), 2 = finish, 3 = both
+static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                             uint64_t n, const mrpdr_wire *wire, void *stream, int phases)
 {
-    if (!check_common("mrpdr_wave_encode", c, f, n)) return 0;
+    if (!check_common(who, c, f, n)) return 0;
     ColsDev cd;
     WireDev wd;
-    if (!fill_cols("mrpdr_wave_encode", f, cols, n, true, &cd)) return 0;
-    if (!fill_wire("mrpdr_wave_encode", f, wire, n, &wd)) return 0;
+    if (!fill_cols(who, f, cols, n, true, &cd)) return 0;
+    if (!fill_wire(who, f, wire, n, &wd)) return 0;
     if (n == 0 || f->dev.nf == 0) return 1;
     hipStream_t st = (hipStream_t)stream;
+    // one-kernel paths have nothing to prepare: they run in the finish phase
     if (rows_path_ok(f, wd)) {
+        if (!(phases & 2)) return 1;
         k_rows_encode<<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, ROWS_PER_BLOCK * wd.stride, st>>>(f->dev, wd, cd, n);
         LAUNCHED("k_rows_encode");
         return 1;
     }
     if (tile_path_ok(f, wd, n)) {
+        if (!(phases & 2)) return 1;
         bool timed;
         if (!perf_begin(c, st, &timed)) return 0;
         k_tile_encode<<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
         LAUNCHED("k_tile_encode");
         return perf_end(c, st, timed, 1);
     }
-    k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
-    LAUNCHED("k_walk_encode");
+    if (phases & 1) {
+        k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
+        LAUNCHED("k_walk_encode");
+        memset(&c->plan, 0, sizeof c->plan);
+        c->plan.fmt = f; c->plan.n = n; c->plan.wire_base = wd.base;
+        if (phases == 1)            // plans for the finish call; a combined call plans as it goes
+            for (int i = 0; i < f->dev.nf; i++)
+                if (f->dev.f[i].kind == MRPDR_ARRAY || f->dev.f[i].kind == MRPDR_STRING)
+                    if (!copy_field<true>(c, f, wd, cd, i, n, false, st, COPY_PLAN)) return 0;
+    }
+    if (!(phases & 2)) return 1;
+    if (phases == 2 && (c->plan.fmt != f || c->plan.n != n || c->plan.wire_base != wd.base))
+        return fail("%s: no matching mrpdr_wave_encode_begin on this ctx", who);
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {
             k_strarr_encode<<<blocks_for(n * 64, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i);
             LAUNCHED("k_strarr_encode");
         } else if (f->dev.f[i].kind != MRPDR_SCALAR) {
-            if (!copy_field<true>(c, f, wd, cd, i, n, false, st)) return 0;
+            if (!copy_field<true>(c, f, wd, cd, i, n, false, st, phases == 2 ? COPY_RUN : COPY_BOTH)) return 0;
         }
     }
+    if (phases == 2) c->plan.fmt = nullptr;
     return 1;
+}
+
+extern "C" int32_t mrpdr_wave_encode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                     uint64_t n, const mrpdr_wire *wire, void *stream)
+{
+    return encode_phases("mrpdr_wave_encode", c, f, cols, n, wire, stream, 3);
+}
+
+extern "C" int32_t mrpdr_wave_encode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                           uint64_t n, const mrpdr_wire *wire, void *stream)
+{
+    return encode_phases("mrpdr_wave_encode_begin", c, f, cols, n, wire, stream, 1);
+}
+
+extern "C" int32_t mrpdr_wave_encode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_column *cols,
+                                            uint64_t n, const mrpdr_wire *wire, void *stream)
+{
+    return encode_phases("mrpdr_wave_encode_finish", c, f, cols, n, wire, stream, 2);
 }
 
 // ---------------------------------------------------------------------------

@@ -282,6 +282,17 @@ class Codec:
                                          C.byref(w), _stream())
         _check(ok, "mrpdr_wave_encode")
 
+    def encode_begin(self, fmt, cols, wire):
+        """Scalars, length prefixes and the plan of the payload streams (reads no array values)."""
+        w = wire.c_struct()
+        _check(self._lib.mrpdr_wave_encode_begin(self.handle, fmt.handle, _c_columns(cols), wire.n,
+                                                 C.byref(w), _stream()), "mrpdr_wave_encode_begin")
+
+    def encode_finish(self, fmt, cols, wire):
+        w = wire.c_struct()
+        _check(self._lib.mrpdr_wave_encode_finish(self.handle, fmt.handle, _c_columns(cols), wire.n,
+                                                  C.byref(w), _stream()), "mrpdr_wave_encode_finish")
+
     def payload_phase(self, fmt, align):
         return int(self._lib.mrpdr_fmt_payload_phase(fmt.handle, align))
 

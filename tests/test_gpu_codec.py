@@ -451,3 +451,37 @@ def test_short_packet_tiles_leave_gaps_alone_and_take_any_order(codec):
     assert np.array_equal(W.Codec.to_numpy(ok), ref_ok)
     assert columns_equal(host_cols(W.Format(fmt_s), dcols, n), ref_cols)
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("fmt_s,n,maxc", [("%af", 40, 30000), ("%d %alf %s %ad", 300, 9000), ("%auc %d", 1000, 20),
+                                          ("%d %lf", 500, 0), ("%as %af", 50, 4000)])
+def test_encode_in_two_calls_on_two_streams(codec, fmt_s, n, maxc):
+    """mrpdr_wave_encode_begin (prefixes + plans, on a side stream, with its own ctx) and
+    mrpdr_wave_encode_finish (payloads) give the bytes of the one-call encode."""
+    ocols = make_wave(fmt_s, n, seed=n + maxc, max_count=maxc)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=16)
+    fmt = W.Format(fmt_s)
+    cols = dev_cols(codec, fmt, ocols)
+    enc = W.Codec(device=codec.device.index, max_packets=1 << 16)
+    packed = fmt.is_fixed
+    if packed:
+        wire = W.WireWave(torch.zeros(n * fmt.fixed_bytes, dtype=torch.uint8, device=codec.device), n, None, None,
+                          fmt.fixed_bytes)
+        arena, _, _ = O.wave_encode(fmt_s, ocols, n)
+    else:
+        dl, do, total = enc.sizeof(fmt, cols, n, 16, 0)
+        wire = W.WireWave(torch.zeros(total, dtype=torch.uint8, device=codec.device), n, do, dl, 0)
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    with torch.cuda.stream(side):
+        side.wait_stream(torch.cuda.current_stream())
+        enc.encode_begin(fmt, cols, wire)
+        ev.record(side)
+    torch.cuda.current_stream().wait_event(ev)
+    enc.encode_finish(fmt, cols, wire)
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[: arena.size], arena)
+    if not packed and not any(k == W.STRING_ARRAY for k in fmt.kinds) and maxc >= 4000:
+        with pytest.raises(W.PdrError):           # finish without a begin
+            enc.encode_finish(fmt, cols, wire)
+    assert enc.status() == 0
