@@ -20,6 +20,7 @@
 #pragma once
 
 #include "common.h"
+#include "rows.h"
 
 #define COPY_UNROLL 4
 #define COPY_PIECE 16u
@@ -141,11 +142,9 @@ __device__ inline void seg_load(Seg &sg, uint64_t s, uint32_t w, const CopyArgs 
 // (DESC_EXTEND: allowed when those bytes are in the same packet); the delta bytes in front
 // of piece 0 were then written by the previous chunk, otherwise DESC_HEAD asks for them.
 template <bool ENCODE>
-__global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt, ColsDev cols,
-                                                         ChunkDesc *desc, uint64_t ndesc)
+__device__ __forceinline__ void plan_chunk(const CopyArgs &a, const FmtDev &fmt, const ColsDev &cols,
+                                           ChunkDesc *desc, uint64_t k)
 {
-    const uint64_t k = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (k >= ndesc) return;
     const uint32_t w = fmt.f[a.field].width;
     const uint64_t total = a.seg_offs[a.n] * w;
     ChunkDesc d;
@@ -173,6 +172,24 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt,
         d.info = ((uint32_t)(ce - cb) << 3) | flags;
     }
     desc[k] = d;
+}
+
+template <bool ENCODE>
+__global__ __launch_bounds__(MRPDR_TPB) void k_copy_plan(CopyArgs a, FmtDev fmt, ColsDev cols,
+                                                         ChunkDesc *desc, uint64_t ndesc)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (k < ndesc) plan_chunk<ENCODE>(a, fmt, cols, desc, k);
+}
+
+// Encode: the prefix walk (one lane per packet) and the chunk plan of one field (one lane per
+// chunk) need the same inputs and nothing of each other: one launch for both.
+__global__ __launch_bounds__(MRPDR_TPB) void k_walk_plan_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n,
+                                                                CopyArgs a, ChunkDesc *desc, uint64_t ndesc)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i < n) walk_encode_packet(fmt, wire, cols, i);
+    if (i < ndesc) plan_chunk<true>(a, fmt, cols, desc, i);
 }
 
 // Move one element at a time: chunk tails and 16-byte pieces that straddle packets.

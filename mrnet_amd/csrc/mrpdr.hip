@@ -200,6 +200,7 @@ struct mrpdr_ctx {
     struct {
         const mrpdr_fmt *fmt; uint64_t n; const uint8_t *wire_base;
         uint32_t used;                      // descriptors taken
+        int32_t  closed;                    // a field did not fit: no further plans
         uint32_t off[MRPDR_MAXF], nd[MRPDR_MAXF];   // per field: where its plan starts, how long (0 = none)
     } plan;
     uint64_t *tile_cnt;       // tile kernels: element totals per (variable field, tile)
@@ -505,7 +506,8 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     const bool by_packet = bound / a.n < 2048;
     if (mode == COPY_PLAN) {
         // the plan of this field behind the plans already taken, when it fits the descriptor buffer
-        if (by_packet || nchunks > DESC_CAP - c->plan.used) return 1;
+        if (by_packet) return 1;
+        if (c->plan.closed || nchunks > DESC_CAP - c->plan.used) { c->plan.closed = 1; return 1; }
         a.first_chunk = 0;
         k_copy_plan<ENCODE><<<blocks_for(nchunks, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc + c->plan.used, nchunks);
         LAUNCHED("k_copy_plan");
@@ -560,20 +562,27 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     return 1;
 }
 
-template <bool ENCODE>
-static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
-                          uint64_t n, bool swap, hipStream_t st, int mode = COPY_BOTH)
+static CopyArgs make_copy_args(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
+                               uint64_t n)
 {
-    const FieldDev &fd = f->dev.f[field];
     CopyArgs a;
     a.wire = wd;
     a.dense = (uint8_t *)cd.values[field];
     a.seg_offs = cd.offs[field];
     a.n = n;
-    a.dense_cap = cd.cap[field] * fd.width;
+    a.dense_cap = cd.cap[field] * f->dev.f[field].width;
     a.status = c->status;
     a.field = field;
     a.first_chunk = 0;
+    return a;
+}
+
+template <bool ENCODE>
+static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
+                          uint64_t n, bool swap, hipStream_t st, int mode = COPY_BOTH)
+{
+    const FieldDev &fd = f->dev.f[field];
+    CopyArgs a = make_copy_args(c, f, wd, cd, field, n);
     if (n == 0 || a.dense_cap == 0) return 1;
     // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
     const bool sw = swap && fd.width > 1 && !ENCODE;
@@ -615,13 +624,36 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
         return perf_end(c, st, timed, 1);
     }
     if (phases & 1) {
-        k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
-        LAUNCHED("k_walk_encode");
         memset(&c->plan, 0, sizeof c->plan);
         c->plan.fmt = f; c->plan.n = n; c->plan.wire_base = wd.base;
-        if (phases == 1)            // plans for the finish call; a combined call plans as it goes
+        // the first field whose payload goes through the chunk kernel: its plan rides along with
+        // the prefix walk, one launch for both
+        int fused = -1;
+        uint64_t nch = 0;
+        for (int i = 0; i < f->dev.nf && fused < 0; i++) {
+            if (f->dev.f[i].kind != MRPDR_ARRAY && f->dev.f[i].kind != MRPDR_STRING) continue;
+            const uint64_t cap = cd.cap[i] * f->dev.f[i].width;
+            const uint64_t bound = wd.bytes < cap ? wd.bytes : cap;
+            if (cap == 0 || bound / n < 2048) continue;        // no payload / the packet-centric kernel
+            nch = (bound + COPY_CHUNK - 1) / COPY_CHUNK;
+            if (nch <= DESC_CAP) fused = i;
+            break;
+        }
+        if (fused >= 0) {
+            const uint64_t lanes = n > nch ? n : nch;
+            k_walk_plan_encode<<<blocks_for(lanes, MRPDR_TPB), MRPDR_TPB, 0, st>>>(
+                f->dev, wd, cd, n, make_copy_args(c, f, wd, cd, fused, n), c->desc, nch);
+            LAUNCHED("k_walk_plan_encode");
+            c->plan.off[fused] = 0;
+            c->plan.nd[fused] = (uint32_t)nch;
+            c->plan.used = (uint32_t)nch;
+        } else {
+            k_walk_encode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n);
+            LAUNCHED("k_walk_encode");
+        }
+        if (phases == 1)            // the other plans for the finish call; a combined call plans them as it goes
             for (int i = 0; i < f->dev.nf; i++)
-                if (f->dev.f[i].kind == MRPDR_ARRAY || f->dev.f[i].kind == MRPDR_STRING)
+                if (i != fused && (f->dev.f[i].kind == MRPDR_ARRAY || f->dev.f[i].kind == MRPDR_STRING))
                     if (!copy_field<true>(c, f, wd, cd, i, n, false, st, COPY_PLAN)) return 0;
     }
     if (!(phases & 2)) return 1;
@@ -632,7 +664,7 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
             k_strarr_encode<<<blocks_for(n * 64, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i);
             LAUNCHED("k_strarr_encode");
         } else if (f->dev.f[i].kind != MRPDR_SCALAR) {
-            if (!copy_field<true>(c, f, wd, cd, i, n, false, st, phases == 2 ? COPY_RUN : COPY_BOTH)) return 0;
+            if (!copy_field<true>(c, f, wd, cd, i, n, false, st, (phases == 2 || c->plan.nd[i]) ? COPY_RUN : COPY_BOTH)) return 0;
         }
     }
     if (phases == 2) c->plan.fmt = nullptr;

@@ -208,10 +208,8 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
 
 // Encode walk: scalars and length prefixes at their running cursor.  Array and
 // string payloads are moved by the segment copy kernel.
-__global__ __launch_bounds__(MRPDR_TPB) void k_walk_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n)
+__device__ __forceinline__ void walk_encode_packet(const FmtDev &fmt, const WireDev &wire, const ColsDev &cols, uint64_t i)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= n) return;
     uint8_t *p = wire.base + pkt_off(wire, i);
     for (int f = 0; f < fmt.nf; f++) {
         const FieldDev fd = fmt.f[f];
@@ -229,4 +227,10 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_encode(FmtDev fmt, WireDev w
             p += 4 + cnt;
         }
     }
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_walk_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i < n) walk_encode_packet(fmt, wire, cols, i);
 }
