@@ -145,8 +145,10 @@ int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host
 
 /* Timing of the payload kernels, the counterpart of the reference's per-filter / per-packet
  * timers (PerfDataMgr, src/PerfDataEvent.C; Packet::start_Timer, src/Filter.C:60-112).
- * While enabled, every payload-kernel launch made through this ctx is bracketed by HIP
- * events on the caller's stream (at most 4096 launches between two collects).
+ * While enabled (on > 0), every on-th payload-kernel launch of each direction made through this
+ * ctx is bracketed by HIP events on the caller's stream (at most 4096 timed launches between two
+ * collects); an event pair costs a few microseconds of stream time, so a caller that also times
+ * the whole stream samples (on = 5: every fifth launch).
  * collect synchronises the stream and returns, for [0] decode and [1] encode payload
  * kernels, the summed elapsed milliseconds and the number of launches, then resets. */
 int32_t     mrpdr_ctx_perf_enable(mrpdr_ctx *ctx, int32_t on);

@@ -212,6 +212,7 @@ struct mrpdr_ctx {
     hipEvent_t *perf_ev;      // PERF_SLOTS pairs
     uint8_t    *perf_kind;    // 0 = decode payload, 1 = encode payload
     uint32_t    perf_used;
+    uint32_t    perf_seen[2];  // payload launches seen per kind since enable (sampling)
 };
 
 #define PERF_SLOTS 4096
@@ -287,10 +288,12 @@ extern "C" int32_t mrpdr_ctx_perf_enable(mrpdr_ctx *c, int32_t on)
         c->perf_ev = (hipEvent_t *)calloc(2 * PERF_SLOTS, sizeof(hipEvent_t));
         c->perf_kind = (uint8_t *)calloc(PERF_SLOTS, 1);
         if (!c->perf_ev || !c->perf_kind) return fail("mrpdr_ctx_perf_enable: out of memory");
-        for (uint32_t i = 0; i < 2 * PERF_SLOTS; i++) HIP_OK(hipEventCreate(&c->perf_ev[i]));
+        for (uint32_t i = 0; i < 2 * PERF_SLOTS; i++)   // timing events without the system-scope cache flush
+            HIP_OK(hipEventCreateWithFlags(&c->perf_ev[i], hipEventDisableSystemFence));
     }
-    c->perf_on = on ? 1 : 0;
+    c->perf_on = on > 0 ? on : 0;          // sampling period: every on-th payload launch of a kind
     c->perf_used = 0;
+    c->perf_seen[0] = c->perf_seen[1] = 0;
     return 1;
 }
 
@@ -436,9 +439,9 @@ static bool tile_path_ok(const mrpdr_fmt *f, const WireDev &w, uint64_t n)
            w.bytes / n <= TILE_AVG_BYTES;
 }
 
-static int32_t perf_begin(mrpdr_ctx *c, hipStream_t st, bool *timed)
+static int32_t perf_begin(mrpdr_ctx *c, hipStream_t st, bool *timed, int kind)
 {
-    *timed = c->perf_on && c->perf_used < PERF_SLOTS;
+    *timed = c->perf_on && c->perf_used < PERF_SLOTS && (c->perf_seen[kind]++ % (uint32_t)c->perf_on) == 0;
     if (*timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
     return 1;
 }
@@ -519,7 +522,7 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     if (mode == COPY_RUN && c->plan.nd[a.field]) {
         const uint32_t nd = c->plan.nd[a.field];
         bool timed;
-        if (!perf_begin(c, st, &timed)) return 0;
+        if (!perf_begin(c, st, &timed, ENCODE ? 1 : 0)) return 0;
         a.first_chunk = 0;
         CopyFast fa = { c->desc + c->plan.off[a.field], a.wire.base, a.dense };
         if (bound >= (32ull << 20)) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
@@ -530,15 +533,11 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     // short payloads (under 2 KiB per packet on average): 16 lanes per packet
     if (by_packet) {
         const uint64_t threads = a.n * PKT_LANES;
-        const bool timed = c->perf_on && c->perf_used < PERF_SLOTS;
-        if (timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
+        bool timed;
+        if (!perf_begin(c, st, &timed, ENCODE ? 1 : 0)) return 0;
         k_copy_packets<W, SWAP, ENCODE><<<blocks_for(threads, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd);
         LAUNCHED("k_copy_packets");
-        if (timed) {
-            HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used + 1], st));
-            c->perf_kind[c->perf_used++] = ENCODE ? 1 : 0;
-        }
-        return 1;
+        return perf_end(c, st, timed, ENCODE ? 1 : 0);
     }
     const uint64_t chunks = nchunks;
     // data this large is touched once per kernel: keep it out of the caches
@@ -548,16 +547,13 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
         a.first_chunk = first;
         k_copy_plan<ENCODE><<<blocks_for(nd, MRPDR_TPB), MRPDR_TPB, 0, st>>>(a, fmt, cd, c->desc, nd);
         LAUNCHED("k_copy_plan");
-        const bool timed = c->perf_on && c->perf_used < PERF_SLOTS;
-        if (timed) HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used], st));
+        bool timed;
+        if (!perf_begin(c, st, &timed, ENCODE ? 1 : 0)) return 0;
         CopyFast fa = { c->desc, a.wire.base, a.dense + first * COPY_CHUNK };
         if (nt) k_copy<W, SWAP, ENCODE, true><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
         else    k_copy<W, SWAP, ENCODE, false><<<nd, MRPDR_TPB, 0, st>>>(fa, a, fmt, cd);
         LAUNCHED("k_copy");
-        if (timed) {
-            HIP_OK(hipEventRecord(c->perf_ev[2 * c->perf_used + 1], st));
-            c->perf_kind[c->perf_used++] = ENCODE ? 1 : 0;
-        }
+        if (!perf_end(c, st, timed, ENCODE ? 1 : 0)) return 0;
     }
     return 1;
 }
@@ -618,7 +614,7 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
     if (tile_path_ok(f, wd, n)) {
         if (!(phases & 2)) return 1;
         bool timed;
-        if (!perf_begin(c, st, &timed)) return 0;
+        if (!perf_begin(c, st, &timed, 1)) return 0;
         k_tile_encode<<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
         LAUNCHED("k_tile_encode");
         return perf_end(c, st, timed, 1);
@@ -766,7 +762,7 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
     if (tile_path_ok(f, wd, n)) {
         bool timed;
-        if (!perf_begin(c, st, &timed)) return 0;
+        if (!perf_begin(c, st, &timed, 0)) return 0;
         const uint32_t tiles = blocks_for(n, TILE_PKTS);
         if (swap) k_tile_decode<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
         else      k_tile_decode<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);

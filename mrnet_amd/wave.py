@@ -362,7 +362,8 @@ class Codec:
         _check(self._lib.mrpdr_ctx_status(self.handle, _stream(), C.byref(s)), "mrpdr_ctx_status")
         return s.value
 
-    def perf_enable(self, on=True):
+    def perf_enable(self, on=1):
+        """on: 0/False = off, k = bracket every k-th payload launch of each direction with events."""
         _check(self._lib.mrpdr_ctx_perf_enable(self.handle, int(on)), "mrpdr_ctx_perf_enable")
 
     def perf_collect(self):
