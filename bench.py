@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: device-resident PDR decode+encode GB/s per wave.
 
-Workload (BASELINE.json config 3, the one the GB/s metric is quoted on): per GPU a wave of
+Workload (the large-array configuration the GB/s metric is quoted on): per GPU a wave of
 4,096 packets, each '%af' with 65,536 floats, written by a BIG-endian sender.  One step =
   decode : walk + count scan + byte-reversing payload kernel  (wire -> float column)
   sizeof : per-packet lengths + offset scan                   (the pdr_sizeof pass)
@@ -531,7 +531,7 @@ def main():
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
     if world > 1:
-        # the one exchange step of the path: BASELINE config 5, a '%lf %d' wave of world x 131,072
+        # the one exchange step of the path: a '%lf %d' wave of world x 131,072
         # packets, fused Avg per shard, results all-gathered (RCCL) and folded in rank order
         from mrnet_amd import dist as D
         n5 = 131072

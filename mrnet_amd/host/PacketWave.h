@@ -19,8 +19,11 @@
 #include <stdint.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mrpdr.h"
@@ -66,6 +69,195 @@ struct HostColumn {
         }
     }
     template <typename T> const T *as() const { return (const T *)values.data(); }
+};
+
+// ---- one packet at a time, the way user code writes it -----------------------------------
+// User code creates packets one by one -- Packet(stream_id, tag, "%d %f %s %ad", 5, 2.5f, "txt",
+// arr, 3u) (src/Packet.C:137-165; the varargs are read by ArgList2DataElementArray, :847-1063)
+// -- and reads them back with unpack(fmt, &a, &b, ...) (:329-353, 1065-1431).  WaveBuilder and
+// WaveReader keep those two call shapes on top of the columns of a wave.  Arguments per token:
+// a scalar takes one arithmetic value (converted to the token's C type: a variadic template has
+// no default promotions to undo), '%s' a const char*, '%aT' / '%AT' a pointer and a length,
+// '%as' a const char* const* and a length.
+struct WaveArg {
+    enum Kind { INT, UINT, FLT, PTR } kind;
+    int64_t i; uint64_t u; double d; const void *p;
+};
+template <typename T> inline WaveArg make_wave_arg(T v)
+{
+    WaveArg a{};
+    if constexpr (std::is_pointer<T>::value || std::is_same<T, std::nullptr_t>::value) { a.kind = WaveArg::PTR; a.p = (const void *)v; }
+    else if constexpr (std::is_floating_point<T>::value) { a.kind = WaveArg::FLT; a.d = (double)v; }
+    else if constexpr (std::is_unsigned<T>::value) { a.kind = WaveArg::UINT; a.u = (uint64_t)v; }
+    else { a.kind = WaveArg::INT; a.i = (int64_t)v; }
+    return a;
+}
+
+class WaveBuilder {
+ public:
+    explicit WaveBuilder(const char *fmt) : fmt_(mrpdr_fmt_compile(fmt)), n_(0)
+    {
+        if (!fmt_) throw PdrError("mrpdr_fmt_compile");
+        cols_.resize(mrpdr_fmt_nfields(fmt_));
+    }
+    ~WaveBuilder() { mrpdr_fmt_free(fmt_); }
+    WaveBuilder(const WaveBuilder &) = delete;
+    WaveBuilder &operator=(const WaveBuilder &) = delete;
+
+    // One packet.  Returns false (and adds nothing) when the arguments do not fit the format --
+    // the reference cannot check that; a NULL string is an encode failure there too (src/pdr.c:280-282).
+    template <typename... A> bool add(A... args)
+    {
+        const WaveArg a[] = { make_wave_arg(args)..., WaveArg{} };
+        return add_args(a, sizeof...(A));
+    }
+    uint64_t size() const { return n_; }
+    const char *format() const { return mrpdr_fmt_string(fmt_); }
+    const std::vector<HostColumn> &columns() const { return cols_; }
+
+ private:
+    static bool scalar_bytes(int type, const WaveArg &a, uint8_t out[8])
+    {
+        if (a.kind == WaveArg::PTR) return false;
+        const double d = a.kind == WaveArg::FLT ? a.d : (a.kind == WaveArg::UINT ? (double)a.u : (double)a.i);
+        const int64_t i = a.kind == WaveArg::FLT ? (int64_t)a.d : (a.kind == WaveArg::UINT ? (int64_t)a.u : a.i);
+        const uint64_t u = a.kind == WaveArg::UINT ? a.u : (uint64_t)i;
+        switch (type) {
+        case MRPDR_CHAR_T:   { int8_t v = (int8_t)i; memcpy(out, &v, 1); return true; }
+        case MRPDR_UCHAR_T:  { uint8_t v = (uint8_t)u; memcpy(out, &v, 1); return true; }
+        case MRPDR_INT16_T:  { int16_t v = (int16_t)i; memcpy(out, &v, 2); return true; }
+        case MRPDR_UINT16_T: { uint16_t v = (uint16_t)u; memcpy(out, &v, 2); return true; }
+        case MRPDR_INT32_T:  { int32_t v = (int32_t)i; memcpy(out, &v, 4); return true; }
+        case MRPDR_UINT32_T: { uint32_t v = (uint32_t)u; memcpy(out, &v, 4); return true; }
+        case MRPDR_INT64_T:  { memcpy(out, &i, 8); return true; }
+        case MRPDR_UINT64_T: { memcpy(out, &u, 8); return true; }
+        case MRPDR_FLOAT_T:  { float v = (float)d; memcpy(out, &v, 4); return true; }
+        case MRPDR_DOUBLE_T: { memcpy(out, &d, 8); return true; }
+        }
+        return false;
+    }
+
+    bool add_args(const WaveArg *a, size_t na)
+    {
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        std::vector<HostColumn> next = cols_;          // all or nothing
+        size_t k = 0;
+        for (int f = 0; f < nf; f++) {
+            const int kind = mrpdr_fmt_field_kind(fmt_, f), w = mrpdr_fmt_field_width(fmt_, f);
+            HostColumn &c = next[f];
+            if (kind == MRPDR_SCALAR) {
+                uint8_t b[8];
+                if (k >= na || !scalar_bytes(mrpdr_fmt_field_type(fmt_, f), a[k++], b)) return false;
+                c.values.insert(c.values.end(), b, b + w);
+            } else if (kind == MRPDR_STRING) {
+                if (k >= na || a[k].kind != WaveArg::PTR || !a[k].p) return false;
+                const char *t = (const char *)a[k++].p;
+                const size_t l = strlen(t) + 1;
+                c.counts.push_back(l);
+                c.values.insert(c.values.end(), (const uint8_t *)t, (const uint8_t *)t + l);
+            } else {
+                if (k + 2 > na || a[k].kind != WaveArg::PTR || a[k + 1].kind == WaveArg::PTR || a[k + 1].kind == WaveArg::FLT) return false;
+                const void *p = a[k].p;
+                const uint64_t len = a[k + 1].kind == WaveArg::UINT ? a[k + 1].u : (uint64_t)a[k + 1].i;
+                k += 2;
+                if (len && !p) return false;
+                c.counts.push_back(len);
+                if (kind == MRPDR_ARRAY) {
+                    c.values.insert(c.values.end(), (const uint8_t *)p, (const uint8_t *)p + len * w);
+                } else {                                   // string array
+                    const char *const *strs = (const char *const *)p;
+                    for (uint64_t j = 0; j < len; j++) {
+                        if (!strs[j]) return false;
+                        const size_t l = strlen(strs[j]) + 1;
+                        c.sub_counts.push_back(l);
+                        c.values.insert(c.values.end(), (const uint8_t *)strs[j], (const uint8_t *)strs[j] + l);
+                    }
+                }
+            }
+        }
+        if (k != na) return false;
+        cols_.swap(next);
+        n_++;
+        return true;
+    }
+
+    mrpdr_fmt *fmt_;
+    uint64_t n_;
+    std::vector<HostColumn> cols_;
+};
+
+// Packet::unpack for packet i of an unpacked wave: scalars are copied out, an array comes back as
+// a malloc'ed copy the caller frees plus its length, a string as a malloc'ed copy -- the ownership
+// rules of DataElementArray2ArgList (src/Packet.C:1065-1431; zero-length array -> NULL).
+class WaveReader {
+ public:
+    WaveReader(const char *fmt, const std::vector<HostColumn> &cols, uint64_t n)
+        : fmt_(mrpdr_fmt_compile(fmt)), cols_(cols), n_(n)
+    {
+        if (!fmt_) throw PdrError("mrpdr_fmt_compile");
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        offs_.resize(nf); sub_offs_.resize(nf);
+        for (int f = 0; f < nf; f++) {
+            if (mrpdr_fmt_field_kind(fmt_, f) == MRPDR_SCALAR) continue;
+            offs_[f].assign(n + 1, 0);
+            for (uint64_t i = 0; i < n; i++) offs_[f][i + 1] = offs_[f][i] + cols[f].counts[i];
+            sub_offs_[f].assign(cols[f].sub_counts.size() + 1, 0);
+            for (size_t j = 0; j < cols[f].sub_counts.size(); j++) sub_offs_[f][j + 1] = sub_offs_[f][j] + cols[f].sub_counts[j];
+        }
+    }
+    ~WaveReader() { mrpdr_fmt_free(fmt_); }
+    WaveReader(const WaveReader &) = delete;
+    WaveReader &operator=(const WaveReader &) = delete;
+
+    // unpack(i, fmt, &a, &b, ...): -1 when fmt differs from the wave's format or i is out of range
+    template <typename... A> int unpack(uint64_t i, const char *fmt, A *...outs)
+    {
+        if (!fmt || strcmp(fmt, mrpdr_fmt_string(fmt_)) != 0 || i >= n_) return -1;
+        void *o[] = { (void *)outs..., nullptr };
+        size_t k = 0;
+        const int nf = mrpdr_fmt_nfields(fmt_);
+        for (int f = 0; f < nf; f++) {
+            const int kind = mrpdr_fmt_field_kind(fmt_, f), w = mrpdr_fmt_field_width(fmt_, f);
+            const HostColumn &c = cols_[f];
+            if (kind == MRPDR_SCALAR) {
+                if (k >= sizeof...(A)) return -1;
+                memcpy(o[k++], c.values.data() + i * w, w);
+            } else if (kind == MRPDR_STRING) {
+                if (k >= sizeof...(A)) return -1;
+                const uint64_t l = c.counts[i];
+                char *t = (char *)malloc(l ? l : 1);
+                memcpy(t, c.values.data() + offs_[f][i], l);
+                *(char **)o[k++] = t;
+            } else {
+                if (k + 2 > sizeof...(A)) return -1;
+                const uint64_t len = c.counts[i];
+                void *copy = nullptr;
+                if (len && kind == MRPDR_ARRAY) {
+                    copy = malloc(len * w);
+                    memcpy(copy, c.values.data() + offs_[f][i] * w, len * w);
+                } else if (len) {
+                    char **strs = (char **)malloc(len * sizeof(char *));
+                    for (uint64_t j = 0; j < len; j++) {
+                        const uint64_t s = offs_[f][i] + j, l = c.sub_counts[s];
+                        strs[j] = (char *)malloc(l);
+                        memcpy(strs[j], c.values.data() + sub_offs_[f][s], l);
+                    }
+                    copy = strs;
+                }
+                *(void **)o[k++] = copy;
+                // '%a*' lengths are 32-bit in the API, '%A*' 64-bit (src/Packet.C:904-934)
+                if (mrpdr_fmt_field_type(fmt_, f) >= MRPDR_CHAR_LRG_ARRAY_T) *(uint64_t *)o[k++] = len;
+                else *(uint32_t *)o[k++] = (uint32_t)len;
+            }
+        }
+        return k == sizeof...(A) ? 0 : -1;
+    }
+
+ private:
+    mrpdr_fmt *fmt_;
+    const std::vector<HostColumn> &cols_;
+    uint64_t n_;
+    std::vector<std::vector<uint64_t> > offs_, sub_offs_;
 };
 
 class DeviceBuffer {

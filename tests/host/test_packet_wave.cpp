@@ -217,6 +217,45 @@ static void test_string_arrays(WaveContext &wc)
     delete got;
 }
 
+// Packets written one at a time, as user code does (tests/test_basic_FE.C sends
+// "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s" with these very values), then read back one at a time.
+static void test_builder_reader(WaveContext &wc)
+{
+    const char *fmt = "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s %ad %As";
+    WaveBuilder b(fmt);
+    const uint64_t nb = 7;
+    bool ok = true;
+    for (uint64_t i = 0; i < nb; i++) {
+        std::vector<int32_t> arr(i, (int32_t)(100 + i));
+        const char *strs[2] = { "first", "second string" };
+        ok = ok && b.add('A', (unsigned char)'B', (int16_t)-17, (uint16_t)17, -17 - (int)i, 17u, (int64_t)-17, (uint64_t)17,
+                         123.23412f, 123.23412, "Test String", arr.data(), (uint32_t)i, strs, (uint64_t)(i % 3));
+    }
+    ok = ok && !b.add(1, 2, 3);                              // wrong argument list: nothing added
+    ok = ok && b.size() == nb;
+    PacketWave sent(wc, (1u << 30) + 10, 101, fmt, b.columns(), nb);
+    PacketWave *got = received(wc, sent);
+    std::vector<HostColumn> out;
+    ok = ok && got->unpack(fmt, out) == 0;
+    WaveReader rd(fmt, out, nb);
+    for (uint64_t i = 0; ok && i < nb; i++) {
+        char c; unsigned char uc; int16_t hd; uint16_t uhd; int32_t d; uint32_t ud; int64_t ld; uint64_t uld;
+        float f; double lf; char *s = nullptr; int32_t *arr = nullptr; uint32_t alen = 99; char **strs = nullptr; uint64_t slen = 99;
+        ok = rd.unpack(i, fmt, &c, &uc, &hd, &uhd, &d, &ud, &ld, &uld, &f, &lf, &s, &arr, &alen, &strs, &slen) == 0;
+        ok = ok && c == 'A' && uc == 'B' && hd == -17 && uhd == 17 && d == -17 - (int)i && ud == 17 && ld == -17 &&
+             uld == 17 && f == 123.23412f && lf == 123.23412 && !strcmp(s, "Test String") && alen == i && slen == i % 3;
+        ok = ok && ((i == 0) == (arr == nullptr));           // zero-length array -> NULL (src/Packet.C:1163-1164)
+        for (uint32_t k = 0; ok && k < alen; k++) ok = arr[k] == (int32_t)(100 + i);
+        if (ok && slen > 0) ok = !strcmp(strs[0], "first");
+        if (ok && slen > 1) ok = !strcmp(strs[1], "second string");
+        for (uint64_t k = 0; strs && k < slen; k++) free(strs[k]);
+        free(strs); free(arr); free(s);
+    }
+    ok = ok && rd.unpack(0, "%d", (int *)nullptr) == -1;     // format mismatch
+    end_SubTest("WaveBuilder / WaveReader (one packet at a time)", ok);
+    delete got;
+}
+
 int main()
 {
     try {
@@ -238,6 +277,7 @@ int main()
         test_filters_known_answers(wc);
         test_truncated(wc);
         test_string_arrays(wc);
+        test_builder_reader(wc);
     } catch (const std::exception &e) {
         printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
         failures++;

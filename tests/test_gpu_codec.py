@@ -351,7 +351,7 @@ def test_headers_with_destination_list(codec):
 
 
 def test_full_size_array_wave_properties(codec):
-    """BASELINE config 3 shape: '%af' with 65,536 floats per packet from a big-endian sender.
+    """The headline shape: '%af' with 65,536 floats per packet from a big-endian sender.
     Size-independent properties: decode(BE) == element-wise byte reversal; encode(decode(x))
     is the little-endian wire; decode(encode(decode(x))) == decode(x)."""
     n, m = 1024, 65536

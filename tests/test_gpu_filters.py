@@ -134,7 +134,7 @@ def test_empty_wave_and_zero_counts(codec):
 
 @pytest.mark.parametrize("shape", [W.SHAPE_FLAT, W.SHAPE_TREE])
 def test_fused_decode_filter_on_the_wire(codec, shape):
-    """BASELINE config 2: 65,536 '%d' packets decoded and summed; config 5 shape '%lf %d'."""
+    """65,536 '%d' packets decoded and summed (the IntegerAddition wave); the '%lf %d' Avg shape."""
     n = 65536
     vals = random_values(np.int32, n, 2)
     cols = [{"type": O.INT32_T, "values": vals}]
@@ -173,7 +173,7 @@ def test_fused_decode_filter_on_the_wire(codec, shape):
 
 @pytest.mark.parametrize("opname,op", OPS)
 def test_sharded_wave_combine(codec, opname, op):
-    """A 1M-packet '%lf %d' wave in 8 packet ranges (BASELINE config 5 shape): per-range tree
+    """A 1M-packet '%lf %d' wave in 8 packet ranges (one per GPU of a node): per-range tree
     result on the GPU, then the rank-ordered last level -- against the oracle doing the same."""
     from mrnet_amd import dist as D
     n, world = 1 << 20, 8
