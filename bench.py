@@ -267,7 +267,16 @@ def small_wave_extras(codec):
         for r, op in zip(r3, (W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
             codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
                              n5, 0, W.SHAPE_TREE, r, rok)
-    out["c5_shard_us_per_wave"] = round(time_call(c5, 200) * 1e6, 2)
+    out["c5_shard_us_per_wave_three_filters"] = round(time_call(c5, 200) * 1e6, 2)
+    r48 = torch.empty(48, dtype=torch.uint8, device=dev)
+    ok3 = torch.empty(3, dtype=torch.int32, device=dev)
+
+    def c5_fused():
+        codec.filter_stats_raw(W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12, n5, 0,
+                               r48, ok3)
+    out["c5_shard_us_per_wave"] = round(time_call(c5_fused, 200) * 1e6, 2)
+    for k in range(3):
+        assert torch.equal(r48[16 * k:16 * k + 16], r3[k]), "fused Min/Max/Avg differs from the separate filters"
     out.update(perfdata_extra(codec))
     out.update(mixed_wave_extra(codec))
     out.update(batched_small_waves_extra(dev))

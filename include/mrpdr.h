@@ -313,6 +313,16 @@ int32_t mrpdr_wave_filter(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shap
                           uint64_t n, int32_t swap,
                           void *result, int32_t *result_ok, void *stream);
 
+/* tfilter_Min, tfilter_Max and tfilter_Avg of one '<T> %d' wave in ONE pass over the packets
+ * (a monitoring stream usually carries all three).  Same arguments as mrpdr_wave_filter with the
+ * declared tree shape; results = 3 x 16 bytes (MIN, MAX, AVG output packets' data), results_ok = 3
+ * flags.  Each result equals that of its own mrpdr_wave_filter(MRPDR_SHAPE_TREE) call bit for bit. */
+int32_t mrpdr_wave_filter_stats(mrpdr_ctx *ctx, int32_t type,
+                                const void *values, uint64_t value_stride,
+                                const void *counts, uint64_t count_stride,
+                                uint64_t n, int32_t swap_bytes,
+                                void *results, int32_t *results_ok, void *stream);
+
 /* ---- array filters ----------------------------------------------------------
  * tfilter_ArrayConcat (src/FilterDefinitions.C:649-810): the output packet carries the arrays of
  * all input packets back to back -- which is what the decoded values column of the wave already

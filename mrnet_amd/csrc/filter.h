@@ -140,26 +140,22 @@ __device__ inline void write_result(uint8_t *result, int32_t *result_ok, bool pr
 }
 
 // ---- tree shape, levels 0..7: one partial per workgroup -------------------------
+// Levels 0..7 for one operator over the packets this lane loaded: level 0 folds the lane's
+// packets in order, levels 1..6 pair neighbours across the wavefront (the lower lane is the left
+// child), level 7 folds the wavefronts of the workgroup.  Thread 0 returns the workgroup's node.
+// Contains workgroup barriers: every thread calls it.
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Partial *partials)
+__device__ inline Partial tile_node(const T *vals, const int32_t *cnts, int nvalid, Partial *wave_part)
 {
-    __shared__ Partial wave_part[MRPDR_TPB / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t first = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)threadIdx.x * FILTER_LEAF;
-
-    // level 0: this lane's packets, in order
     Folder<OP, T> fo;
     fo.init();
 #pragma unroll
-    for (int k = 0; k < FILTER_LEAF; k++) {
-        const uint64_t i = first + k;
-        if (i < in.n) fo.add(load_value<T>(in, i), OP == MRPDR_AVG ? load_count(in, i) : 1);
-    }
+    for (int k = 0; k < FILTER_LEAF; k++)
+        if (k < nvalid) fo.add(vals[k], OP == MRPDR_AVG ? cnts[k] : 1);
     bool present = fo.finish();
     T v = fo.res;
     int32_t cnt = fo.cnt;
-
-    // levels 1..6: pair neighbours across the wavefront; the lower lane is the left child
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
         const uint64_t ob = __shfl_xor((unsigned long long)to_bits<T>(v), m, 64);
@@ -176,48 +172,154 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Par
         present = g.finish();
         v = g.res; cnt = g.cnt;
     }
-
-    // level 7: the wavefronts of this workgroup
+    __syncthreads();                     // wave_part may still be read from the previous operator
     if (lane == 0) {
         wave_part[wave].bits = to_bits<T>(v);
         wave_part[wave].cnt = cnt;
         wave_part[wave].present = present ? 1 : 0;
     }
     __syncthreads();
+    Partial out;
+    out.bits = 0; out.cnt = 0; out.present = 0;
     if (threadIdx.x == 0) {
         Folder<OP, T> g;
         g.init();
         for (int w = 0; w < MRPDR_TPB / 64; w++)
             if (wave_part[w].present) g.add(from_bits<T>(wave_part[w].bits), wave_part[w].cnt);
-        Partial out;
         out.present = g.finish() ? 1 : 0;
         out.bits = to_bits<T>(g.res);
         out.cnt = g.cnt;
-        partials[blockIdx.x] = out;
+    }
+    return out;
+}
+
+// This lane's packets: values and (with COUNTS) counts; returns how many there are.
+template <typename T, bool COUNTS>
+__device__ inline int tile_load(const FilterIn &in, T *vals, int32_t *cnts)
+{
+    const uint64_t first = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)threadIdx.x * FILTER_LEAF;
+    int nvalid = 0;
+#pragma unroll
+    for (int k = 0; k < FILTER_LEAF; k++) {
+        const uint64_t i = first + k;
+        vals[k] = T();
+        cnts[k] = 1;
+        if (i < in.n) {
+            vals[k] = load_value<T>(in, i);
+            if (COUNTS) cnts[k] = load_count(in, i);
+            nvalid = k + 1;
+        }
+    }
+    return nvalid;
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Partial *partials)
+{
+    __shared__ Partial wave_part[MRPDR_TPB / 64];
+    T vals[FILTER_LEAF];
+    int32_t cnts[FILTER_LEAF];
+    const int nvalid = tile_load<T, OP == MRPDR_AVG>(in, vals, cnts);
+    const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
+    if (threadIdx.x == 0) partials[blockIdx.x] = out;
+}
+
+// One lane folds m staged nodes in order.  Eight LDS reads are issued before the first of them is
+// used: the fold is a dependent chain, the reads need not be.
+template <int OP, typename T>
+__device__ inline void fold_nodes(Folder<OP, T> &g, const Partial *stage, uint32_t m)
+{
+    for (uint32_t k = 0; k < m; k += 8) {
+        Partial p[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            p[j].present = 0;
+            if (k + j < m) p[j] = stage[k + j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (p[j].present) g.add(from_bits<T>(p[j].bits), p[j].cnt);
     }
 }
 
 // ---- tree shape, last level: all workgroup partials, in order ---------------------
+// Contains workgroup barriers: every thread calls it.
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_top(const Partial *partials, uint64_t np,
-                                                               uint8_t *result, int32_t *result_ok)
+__device__ inline void tree_top(const Partial *partials, uint64_t np, uint8_t *result, int32_t *result_ok,
+                                Partial *stage)
 {
-    __shared__ Partial stage[FLAT_TILE];
     Folder<OP, T> g;
     g.init();
     for (uint64_t base = 0; base < np; base += FLAT_TILE) {
         const uint32_t m = (uint32_t)((np - base) < FLAT_TILE ? (np - base) : FLAT_TILE);
+        __syncthreads();
         for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) stage[k] = partials[base + k];
         __syncthreads();
-        if (threadIdx.x == 0)
-            for (uint32_t k = 0; k < m; k++)
-                if (stage[k].present) g.add(from_bits<T>(stage[k].bits), stage[k].cnt);
-        __syncthreads();
+        if (threadIdx.x == 0) fold_nodes<OP, T>(g, stage, m);
     }
     if (threadIdx.x == 0) {
         const bool present = g.finish();
         write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
     }
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_top(const Partial *partials, uint64_t np,
+                                                               uint8_t *result, int32_t *result_ok)
+{
+    __shared__ Partial stage[FLAT_TILE];
+    tree_top<OP, T>(partials, np, result, result_ok, stage);
+}
+
+// ---- Min, Max and Avg of one '<T> %d' wave in one pass ------------------------------
+// The packets are read once; each operator then goes through the same tree as on its own
+// (same fan-ins, same order), so the three results equal those of three separate filters.
+// partials: three runs of `stride` nodes (MIN, MAX, AVG); results: 3 x 16 bytes; oks: 3.
+template <typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_stats_tile(FilterIn in, Partial *partials, uint64_t stride)
+{
+    __shared__ Partial wave_part[MRPDR_TPB / 64];
+    T vals[FILTER_LEAF];
+    int32_t cnts[FILTER_LEAF];
+    const int nvalid = tile_load<T, true>(in, vals, cnts);
+    const Partial a = tile_node<MRPDR_MIN, T>(vals, cnts, nvalid, wave_part);
+    const Partial b = tile_node<MRPDR_MAX, T>(vals, cnts, nvalid, wave_part);
+    const Partial c = tile_node<MRPDR_AVG, T>(vals, cnts, nvalid, wave_part);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = a;
+        partials[stride + blockIdx.x] = b;
+        partials[2 * stride + blockIdx.x] = c;
+    }
+}
+
+#define STATS_TILE 1024                 // nodes of each operator staged per step (3 x 16 KiB of LDS)
+
+template <typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_stats_top(const Partial *partials, uint64_t np, uint64_t stride,
+                                                                uint8_t *results, int32_t *oks)
+{
+    // the three folds are independent chains: lane 0 of wavefronts 0, 1, 2 takes one each
+    __shared__ Partial stage[3][STATS_TILE];
+    const int mine = (threadIdx.x & 63) == 0 ? (int)(threadIdx.x >> 6) : 3;
+    Folder<MRPDR_MIN, T> gmin;
+    Folder<MRPDR_MAX, T> gmax;
+    Folder<MRPDR_AVG, T> gavg;
+    gmin.init(); gmax.init(); gavg.init();
+    for (uint64_t base = 0; base < np; base += STATS_TILE) {
+        const uint32_t m = (uint32_t)((np - base) < STATS_TILE ? (np - base) : STATS_TILE);
+        __syncthreads();
+        for (uint32_t k = threadIdx.x; k < 3 * m; k += MRPDR_TPB) {
+            const uint32_t o = k / m, j = k - o * m;
+            stage[o][j] = partials[o * stride + base + j];
+        }
+        __syncthreads();
+        if (mine == 0) fold_nodes<MRPDR_MIN, T>(gmin, stage[0], m);
+        else if (mine == 1) fold_nodes<MRPDR_MAX, T>(gmax, stage[1], m);
+        else if (mine == 2) fold_nodes<MRPDR_AVG, T>(gavg, stage[2], m);
+    }
+    if (mine == 0) { const bool p = gmin.finish(); write_result<MRPDR_MIN, T>(results, oks, p, gmin.res, gmin.cnt); }
+    if (mine == 1) { const bool p = gmax.finish(); write_result<MRPDR_MAX, T>(results + 16, oks + 1, p, gmax.res, gmax.cnt); }
+    if (mine == 2) { const bool p = gavg.finish(); write_result<MRPDR_AVG, T>(results + 32, oks + 2, p, gavg.res, gavg.cnt); }
 }
 
 // ---- flat shape: one left fold over the whole wave ------------------------------

@@ -232,7 +232,7 @@ extern "C" mrpdr_ctx *mrpdr_ctx_create(int32_t device, uint64_t max_packets)
     const size_t o_status = 0, o_totals = 256;
     const size_t o_sums = o_totals + 256 * sizeof(uint64_t);
     const size_t o_part = o_sums + ((c->ntile_sums * sizeof(uint64_t) + 255) & ~(size_t)255);
-    const size_t o_desc = (o_part + c->npartials * sizeof(Partial) + 255) & ~(size_t)255;
+    const size_t o_desc = (o_part + 3 * c->npartials * sizeof(Partial) + 255) & ~(size_t)255;   // x3: the stats filter
     const size_t o_pktb = o_desc + (size_t)DESC_CAP * sizeof(ChunkDesc);
     const size_t o_pkto = o_pktb + (((c->max_packets + 1) * sizeof(uint64_t) + 255) & ~(size_t)255);
     c->ntile_cnt = (c->max_packets + TILE_PKTS - 1) / TILE_PKTS + 1;
@@ -968,6 +968,45 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     }
     // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
     return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
+}
+
+template <typename T>
+static int32_t run_stats(mrpdr_ctx *c, const FilterIn &in, uint8_t *results, int32_t *oks, hipStream_t st)
+{
+    const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
+    if (tiles) {
+        k_filter_stats_tile<T><<<tiles, MRPDR_TPB, 0, st>>>(in, c->partials, c->npartials);
+        LAUNCHED("k_filter_stats_tile");
+    }
+    k_filter_stats_top<T><<<1, MRPDR_TPB, 0, st>>>(c->partials, tiles, c->npartials, results, oks);
+    LAUNCHED("k_filter_stats_top");
+    return 1;
+}
+
+extern "C" int32_t mrpdr_wave_filter_stats(mrpdr_ctx *c, int32_t type, const void *values, uint64_t value_stride,
+                                           const void *counts, uint64_t count_stride, uint64_t n, int32_t swap,
+                                           void *results, int32_t *results_ok, void *stream)
+{
+    if (!c) return fail("mrpdr_wave_filter_stats: NULL ctx");
+    if (n > c->max_packets) return fail("mrpdr_wave_filter_stats: n exceeds the ctx limit");
+    if (!results || !results_ok) return fail("mrpdr_wave_filter_stats: NULL result");
+    if (n && (!values || !counts)) return fail("mrpdr_wave_filter_stats: NULL values or counts");
+    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
+    uint8_t *res = (uint8_t *)results;
+    hipStream_t st = (hipStream_t)stream;
+    switch (type) {
+    case MRPDR_CHAR_T:   return run_stats<int8_t>(c, in, res, results_ok, st);
+    case MRPDR_UCHAR_T:  return run_stats<uint8_t>(c, in, res, results_ok, st);
+    case MRPDR_INT16_T:  return run_stats<int16_t>(c, in, res, results_ok, st);
+    case MRPDR_UINT16_T: return run_stats<uint16_t>(c, in, res, results_ok, st);
+    case MRPDR_INT32_T:  return run_stats<int32_t>(c, in, res, results_ok, st);
+    case MRPDR_UINT32_T: return run_stats<uint32_t>(c, in, res, results_ok, st);
+    case MRPDR_INT64_T:  return run_stats<int64_t>(c, in, res, results_ok, st);
+    case MRPDR_UINT64_T: return run_stats<uint64_t>(c, in, res, results_ok, st);
+    case MRPDR_FLOAT_T:  return run_stats<float>(c, in, res, results_ok, st);
+    case MRPDR_DOUBLE_T: return run_stats<double>(c, in, res, results_ok, st);
+    }
+    return fail("mrpdr_wave_filter_stats: type %d is not a scalar the filters accept", type);
 }
 
 // ---------------------------------------------------------------------------

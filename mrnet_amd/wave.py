@@ -473,6 +473,16 @@ class Codec:
         _check(r, "mrpdr_wave_filter")
         return result, result_ok
 
+    def filter_stats_raw(self, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,
+                         results=None, results_ok=None):
+        """Min, Max and Avg of a '<T> %d' wave in one pass: (uint8[48], int32[3])."""
+        results = self.empty(48, torch.uint8) if results is None else results
+        results_ok = self.empty(3, torch.int32) if results_ok is None else results_ok
+        r = self._lib.mrpdr_wave_filter_stats(self.handle, int(dtype), values_ptr, value_stride, counts_ptr,
+                                              count_stride, n, swap, _ptr(results), _ptr(results_ok), _stream())
+        _check(r, "mrpdr_wave_filter_stats")
+        return results, results_ok
+
     # ---- array filters -------------------------------------------------------------------
     def array_concat(self, col, n):
         """tfilter_ArrayConcat on a decoded array field: the Column of the ONE output packet

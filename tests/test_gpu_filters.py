@@ -243,3 +243,24 @@ def test_bitwise_or_and_integer_percentiles(codec):
         assert (int(raw[:8].view(np.uint64)[0]), int(raw[8:12].view(np.uint32)[0]), int(raw[12:16].view(np.uint32)[0])) \
             == (sbits, smax, smin)
         assert out.get_Tag() == P.PROT_WAVE
+
+
+@pytest.mark.parametrize("tok,t,dt", TYPES)
+def test_fused_min_max_avg_equals_the_three_filters(codec, tok, t, dt):
+    """mrpdr_wave_filter_stats reads the wave once; each of its results is the bytes of the
+    separate tree-shaped filter (which the other tests hold against the oracle)."""
+    for n in (0, 1, 5, 1023, 1025, 70000):
+        vals = values_for(dt, n, 3 * n + t, W.TFILTER_AVG) if n else np.zeros(0, dt)
+        cnt = counts_for(n, n) if n else np.zeros(0, np.int32)
+        w = np.dtype(dt).itemsize
+        rows = np.zeros((n, w + 4), np.uint8)
+        if n:
+            rows[:, :w] = vals.view(np.uint8).reshape(n, w)
+            rows[:, w:] = cnt.view(np.uint8).reshape(n, 4)
+        d = codec.to_device(rows.reshape(-1)) if n else codec.empty(16, torch.uint8)
+        base = d.data_ptr()
+        res, oks = codec.filter_stats_raw(t, base, w + 4, base + w, w + 4, n)
+        for k, op in enumerate((W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
+            one, ok1 = codec.filter_raw(op, t, base, w + 4, base + w, w + 4, n, 0, W.SHAPE_TREE)
+            assert int(oks[k].item()) == int(ok1.item()), (tok, n, op)
+            assert torch.equal(res[16 * k:16 * k + 16], one), (tok, n, op)
