@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from wavegen import O, columns_equal, make_wave, to_sender_order
+from wavegen import O, columns_equal, make_wave, splitmix64, to_sender_order
 
 pytestmark = pytest.mark.gpu
 
@@ -485,3 +485,27 @@ def test_encode_in_two_calls_on_two_streams(codec, fmt_s, n, maxc):
         with pytest.raises(W.PdrError):           # finish without a begin
             enc.encode_finish(fmt, cols, wire)
     assert enc.status() == 0
+
+
+@pytest.mark.parametrize("n,align,phase", [(32769, 1, 0), (100000, 16, 0), (300001, 8, 3), (1 << 20, 1, 45)])
+def test_sizeof_large_waves(codec, n, align, phase):
+    """Above 32,768 packets sizing and offsets take two launches (workgroup sums, then offsets);
+    repeated calls reuse the same workspace."""
+    fmt_s = "%d %s %auc"
+    fmt = W.Format(fmt_s)
+    slen = (splitmix64(n, n) % np.uint64(20) + np.uint64(1)).astype(np.uint64)
+    alen = (splitmix64(n + 1, n) % np.uint64(300)).astype(np.uint64)
+    so = np.zeros(n + 1, np.uint64); np.cumsum(slen, out=so[1:])
+    ao = np.zeros(n + 1, np.uint64); np.cumsum(alen, out=ao[1:])
+    cols = [W.Column(codec.empty(n, torch.int32)),
+            W.Column(codec.empty(1, torch.int8), codec.to_device(slen), codec.to_device(so), int(so[n])),
+            W.Column(codec.empty(1, torch.int8), codec.to_device(alen), codec.to_device(ao), int(ao[n]))]
+    want_lens = np.uint64(4 + 4 + 8) + slen + alen
+    want_offs = O.scan_offsets(want_lens, align, phase)
+    big = W.Codec(device=codec.device.index, max_packets=1 << 20)
+    for _ in range(3):
+        lens, offs, total = big.sizeof(fmt, cols, n, align, phase)
+        assert np.array_equal(W.Codec.to_numpy(lens).view(np.uint64), want_lens)
+        assert np.array_equal(W.Codec.to_numpy(offs).view(np.uint64), want_offs)
+        assert total == int(want_offs[n])
+    assert big.status() == 0
