@@ -1,0 +1,91 @@
+"""Randomly drawn format strings (every token kind, 1-12 tokens), wave sizes, arena layouts and
+sender byte orders: device encode / decode against the oracle, bit for bit.  Seeds are fixed."""
+import numpy as np
+import pytest
+import torch
+
+from wavegen import O, columns_equal, make_wave, splitmix64, to_sender_order
+from test_gpu_codec import dev_cols, host_cols, wire_from_numpy
+
+pytestmark = pytest.mark.gpu
+
+from mrnet_amd import wave as W  # noqa: E402
+
+SCALARS = ["c", "uc", "hd", "uhd", "d", "ud", "ld", "uld", "f", "lf"]
+VARS = ["s", "as", "As"] + ["a" + t for t in SCALARS] + ["A" + t for t in SCALARS]
+SEPS = [" ", "  ", "\t", " \n"]
+
+
+def draw(seed):
+    r = splitmix64(seed, 64)
+    ntok = int(r[0] % np.uint64(12)) + 1
+    p_var = [0.0, 0.3, 0.6][int(r[1] % np.uint64(3))]
+    toks = []
+    for k in range(ntok):
+        if (int(r[2 + k]) % 1000) / 1000.0 < p_var:
+            toks.append(VARS[int(r[20 + k] % np.uint64(len(VARS)))])
+        else:
+            toks.append(SCALARS[int(r[20 + k] % np.uint64(len(SCALARS)))])
+    fmt = "%" + toks[0]
+    for k in range(1, ntok):
+        fmt += SEPS[int(r[40 + k] % np.uint64(len(SEPS)))] + "%" + toks[k]
+    n = [0, 1, 2, 63, 64, 65, 300, 1025, 4000][int(r[60] % np.uint64(9))]
+    max_count = [0, 1, 5, 40, 700][int(r[61] % np.uint64(5))]
+    align = [1, 2, 8, 16, 128][int(r[62] % np.uint64(5))]
+    phase = int(r[63] % np.uint64(align)) if align > 1 else [0, 29][int(r[63] % np.uint64(2))]
+    return fmt, n, max_count, align, phase
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_format_round_trip(codec, seed):
+    fmt_s, n, max_count, align, phase = draw(1000 + seed)
+    if n * max_count > 400000:
+        max_count = 40
+    ocols = make_wave(fmt_s, n, seed, max_count=max_count)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align, phase=phase)
+    fmt = W.Format(fmt_s)
+    cols = dev_cols(codec, fmt, ocols)
+    dl, do, total = codec.sizeof(fmt, cols, n, align, phase)
+    if fmt.is_fixed:
+        # the packed closed form lays packets out by the same rule
+        assert np.array_equal(W.Codec.to_numpy(do).view(np.uint64), offs)
+    else:
+        assert np.array_equal(W.Codec.to_numpy(dl).view(np.uint64), lens), fmt_s
+        assert np.array_equal(W.Codec.to_numpy(do).view(np.uint64), offs), fmt_s
+    assert total == int(offs[n])
+    wire = W.WireWave(torch.zeros(max(total, 1), dtype=torch.uint8, device=codec.device), n, do,
+                      dl if not fmt.is_fixed else codec.to_device(lens) if n else dl, 0)
+    codec.encode_into(fmt, cols, wire)
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[: arena.size], arena), (fmt_s, n, align, phase)
+    bo = W.BIGENDIAN if seed % 2 else W.LITTLEENDIAN
+    src = to_sender_order(fmt_s, arena, offs, lens) if bo == W.BIGENDIAN else arena
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, lens), bo)
+    assert bool(ok.all()) if n else True
+    assert columns_equal(host_cols(fmt, dcols, n), ocols), (fmt_s, n, bo)
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_truncation(codec, seed):
+    """Every packet cut at a random length (a third of them left whole): per-packet ok flags and
+    the columns of what did decode, against the oracle."""
+    fmt_s, n, max_count, _, _ = draw(5000 + seed)
+    n = max(n, 65)
+    if n * max_count > 200000:
+        max_count = 40
+    ocols = make_wave(fmt_s, n, seed, max_count=max_count)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    r = splitmix64(77 + seed, n)
+    cut = np.where(r % np.uint64(3) == 0, lens, r % (lens + np.uint64(1))).astype(np.uint64)
+    bo = W.BIGENDIAN if seed % 2 else W.LITTLEENDIAN
+    src = to_sender_order(fmt_s, arena, offs, lens) if bo == W.BIGENDIAN else arena
+    ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, cut, bo)
+    fmt = W.Format(fmt_s)
+    if fmt.is_fixed:
+        wire = wire_from_numpy(codec, n, src, None, cut, stride=fmt.fixed_bytes)
+    else:
+        wire = wire_from_numpy(codec, n, src, offs, cut)
+    dcols, ok = codec.decode(fmt, wire, bo)
+    assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
+    assert columns_equal(host_cols(fmt, dcols, n), ref_cols), fmt_s
