@@ -355,6 +355,20 @@ int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,
                             uint64_t *out_len, int32_t *out_rank,
                             void *scratch, uint64_t scratch_bytes, void *stream);
 
+/* tfilter_IntEqClass (src/FilterDefinitions.C:812-902) over a decoded wave of "%aud %aud %aud"
+ * packets (class values, members per class, members): the classes of all packets merged by
+ * value, ascending; the members of a class in arrival order (packet order, then class order
+ * inside a packet) -- what the reference's std::map<unsigned, std::vector<unsigned>> yields.
+ * vals / memcnts / mems are the columns of fields 0, 1, 2 (vals->capacity bounds the number of
+ * class entries, 2^32 at most); the three outputs are the columns of the ONE output packet
+ * (counts[1], offs[2], values with capacity: too small sets status bit 0 and empty outputs).
+ * scratch: mrpdr_eqclass_scratch_bytes(vals->capacity) bytes, 16-byte aligned. */
+uint64_t mrpdr_eqclass_scratch_bytes(uint64_t class_capacity);
+int32_t mrpdr_wave_int_eq_class(mrpdr_ctx *ctx, const mrpdr_column *vals, const mrpdr_column *memcnts,
+                                const mrpdr_column *mems, uint64_t n,
+                                mrpdr_column *out_vals, mrpdr_column *out_memcnts, mrpdr_column *out_mems,
+                                void *scratch, uint64_t scratch_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,7 @@
 #include "message.h"
 #include "strarr.h"
 #include "tile.h"
+#include "eqclass.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1115,4 +1116,77 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
     }
     // PerfDataMgr metrics are uint64, int64 or double (src/FilterDefinitions.C:937-953)
     return fail("mrpdr_wave_perfdata: type %d is not a performance-data type", type);
+}
+
+// ---------------------------------------------------------------------------
+// tfilter_IntEqClass
+// ---------------------------------------------------------------------------
+static uint64_t eq_pad(uint64_t entries)
+{
+    uint64_t k = EQ_LOCAL;
+    while (k < entries) k <<= 1;
+    return k;
+}
+
+extern "C" uint64_t mrpdr_eqclass_scratch_bytes(uint64_t class_capacity)
+{
+    return 7 * (eq_pad(class_capacity) + 2) * sizeof(uint64_t);
+}
+
+extern "C" int32_t mrpdr_wave_int_eq_class(mrpdr_ctx *c, const mrpdr_column *vals, const mrpdr_column *memcnts,
+                                           const mrpdr_column *mems, uint64_t n,
+                                           mrpdr_column *out_vals, mrpdr_column *out_memcnts, mrpdr_column *out_mems,
+                                           void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    if (!c || !vals || !memcnts || !mems || !out_vals || !out_memcnts || !out_mems)
+        return fail("mrpdr_wave_int_eq_class: NULL argument");
+    if (n == 0) return fail("mrpdr_wave_int_eq_class: empty wave (the reference emits nothing useful)");
+    if (n > c->max_packets) return fail("mrpdr_wave_int_eq_class: n exceeds the ctx limit");
+    if (!vals->offs || !mems->offs) return fail("mrpdr_wave_int_eq_class: columns need offs");
+    const mrpdr_column *outs[3] = { out_vals, out_memcnts, out_mems };
+    for (int k = 0; k < 3; k++)
+        if (!outs[k]->counts || !outs[k]->offs || (outs[k]->capacity && !outs[k]->values))
+            return fail("mrpdr_wave_int_eq_class: output column %d needs counts, offs and values", k);
+    if (out_memcnts->capacity < out_vals->capacity) return fail("mrpdr_wave_int_eq_class: out_memcnts smaller than out_vals");
+    const uint64_t entries = vals->capacity;          // upper bound of the class entries of the wave
+    const uint64_t kpad = eq_pad(entries);
+    if (kpad > c->max_packets) return fail("mrpdr_wave_int_eq_class: %llu class entries exceed the ctx limit",
+                                           (unsigned long long)entries);
+    if (!scratch || scratch_bytes < mrpdr_eqclass_scratch_bytes(entries) || ((uintptr_t)scratch & 15u))
+        return fail("mrpdr_wave_int_eq_class: needs %llu bytes of 16-byte aligned scratch",
+                    (unsigned long long)mrpdr_eqclass_scratch_bytes(entries));
+    hipStream_t st = (hipStream_t)stream;
+    uint64_t *keys = (uint64_t *)scratch, *cnt64 = keys + kpad + 2, *head = cnt64 + kpad + 2,
+             *sorted_cnt = head + kpad + 2, *class_scan = sorted_cnt + kpad + 2, *dst_off = class_scan + kpad + 2,
+             *src_off = dst_off + kpad + 2;
+    const uint32_t blocks = blocks_for(kpad, MRPDR_TPB), tiles = blocks_for(kpad, EQ_LOCAL);
+    k_eq_keys<<<blocks, MRPDR_TPB, 0, st>>>((const uint32_t *)vals->values, vals->offs, n, kpad, keys,
+                                            (const uint32_t *)memcnts->values, cnt64);
+    LAUNCHED("k_eq_keys");
+    if (!run_scan(c, cnt64, kpad, 1, 0, src_off, st)) return 0;
+    // bitonic network: merges up to EQ_LOCAL inside LDS, then per merge size the far steps over
+    // global memory and the near steps in LDS again
+    k_eq_bitonic_local<<<tiles, MRPDR_TPB, 0, st>>>(keys, kpad, 2, EQ_LOCAL);
+    LAUNCHED("k_eq_bitonic_local");
+    for (uint64_t k = 2 * EQ_LOCAL; k <= kpad; k <<= 1) {
+        for (uint64_t j = k >> 1; j >= EQ_LOCAL; j >>= 1) {
+            k_eq_bitonic_global<<<blocks, MRPDR_TPB, 0, st>>>(keys, kpad, j, k);
+            LAUNCHED("k_eq_bitonic_global");
+        }
+        k_eq_bitonic_local<<<tiles, MRPDR_TPB, 0, st>>>(keys, kpad, k, k);
+        LAUNCHED("k_eq_bitonic_local");
+    }
+    k_eq_heads<<<blocks, MRPDR_TPB, 0, st>>>(keys, vals->offs, n, kpad, cnt64, head, sorted_cnt);
+    LAUNCHED("k_eq_heads");
+    if (!run_scan(c, head, kpad, 1, 0, class_scan, st)) return 0;
+    if (!run_scan(c, sorted_cnt, kpad, 1, 0, dst_off, st)) return 0;
+    EqOut o;
+    o.values = (uint32_t *)out_vals->values; o.memcnts = (uint32_t *)out_memcnts->values; o.mems = (uint32_t *)out_mems->values;
+    o.values_cap = out_vals->capacity; o.mems_cap = out_mems->capacity;
+    for (int k = 0; k < 3; k++) { o.counts[k] = outs[k]->counts; o.offs[k] = outs[k]->offs; }
+    o.status = c->status;
+    k_eq_emit<<<blocks, MRPDR_TPB, 0, st>>>(keys, vals->offs, n, kpad, head, class_scan, dst_off, src_off, sorted_cnt,
+                                            (const uint32_t *)mems->values, o);
+    LAUNCHED("k_eq_emit");
+    return 1;
 }

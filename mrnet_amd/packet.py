@@ -236,6 +236,18 @@ def tfilter_PerfData(ipackets, aggr_id, group=0):
     return _from_columns(ipackets, fmt, out_cols)
 
 
+def tfilter_IntEqClass(ipackets):
+    """src/FilterDefinitions.C:812-902: one '%aud %aud %aud' packet with the equivalence classes
+    of all inputs merged by value."""
+    fmt = ipackets.fmt
+    if fmt.text != "%aud %aud %aud" or ipackets.n == 0 or ipackets.has_Error():
+        return None
+    cols = ipackets.unpack(fmt.text)
+    if ipackets.has_Error():
+        return None
+    return _from_columns(ipackets, fmt, ipackets.codec.int_eq_class(cols[0], cols[1], cols[2], ipackets.n))
+
+
 def BitsetOr(ipackets, shape=W.SHAPE_TREE):
     """Examples/FaultRecovery/FaultRecoveryFilter.C:107-128: one '%uld' packet, the OR of all inputs."""
     if ipackets.fmt.text != "%uld":

@@ -511,6 +511,22 @@ class Codec:
         _check(r, "mrpdr_wave_perfdata")
         return out, out_len, out_rank
 
+    def int_eq_class(self, vals, memcnts, mems, n):
+        """tfilter_IntEqClass over the three decoded '%aud' columns of a wave: the columns of the
+        one output packet (values, members per class, members).  Outputs are sized by the inputs
+        (there cannot be more classes or members than came in)."""
+        kcap, mcap = max(int(vals.capacity), 1), max(int(mems.capacity), 1)
+        outs = [Column(self.empty(cap, torch.int32), self.empty(1, torch.int64), self.empty(2, torch.int64), cap)
+                for cap in (kcap, kcap, mcap)]
+        need = int(self._lib.mrpdr_eqclass_scratch_bytes(int(vals.capacity)))
+        scratch = self.empty(need, torch.uint8)
+        cs = [x.c_struct() for x in (vals, memcnts, mems)] + [x.c_struct() for x in outs]
+        r = self._lib.mrpdr_wave_int_eq_class(self.handle, C.byref(cs[0]), C.byref(cs[1]), C.byref(cs[2]), n,
+                                              C.byref(cs[3]), C.byref(cs[4]), C.byref(cs[5]),
+                                              _ptr(scratch), need, _stream())
+        _check(r, "mrpdr_wave_int_eq_class")
+        return outs
+
     def filter_columns(self, op, dtype, values, counts=None, shape=SHAPE_TREE):
         """Filter over decoded columns: values = T[n] tensor, counts = int32[n] (AVG)."""
         n = values.numel()

@@ -98,6 +98,8 @@ def lib():
         L.orc_filter_perfdata.argtypes = [C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, C.c_uint64,
                                           C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
         L.orc_filter_perfdata.restype = C.c_int32
+        L.orc_filter_int_eq_class.argtypes = [vp] * 6 + [C.c_uint64, vp, vp, vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_filter_int_eq_class.restype = C.c_int32
         L.orc_byte_swap.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
         L.orc_byte_swap.restype = None
         _lib = L
@@ -354,3 +356,18 @@ def filter_perfdata_tree(op, t, ranks, data, fanins):
     if dc.size != 1:
         return None
     return (int(rv[0]) if rv.size else 0), dv
+
+
+def filter_int_eq_class(vals, memcnts, mems):
+    """tfilter_IntEqClass (src/FilterDefinitions.C:812-902).  vals / memcnts / mems are
+    (counts, values) pairs of the three '%aud' fields; returns (values, memcnts, mems)."""
+    vc, vv = np.ascontiguousarray(vals[0], np.uint64), np.ascontiguousarray(vals[1], np.uint32)
+    mv = np.ascontiguousarray(memcnts[1], np.uint32)
+    ec, ev = np.ascontiguousarray(mems[0], np.uint64), np.ascontiguousarray(mems[1], np.uint32)
+    vo = np.zeros(vc.size + 1, np.uint64); np.cumsum(vc, out=vo[1:])
+    eo = np.zeros(ec.size + 1, np.uint64); np.cumsum(ec, out=eo[1:])
+    ov, om, oe = np.zeros(max(vv.size, 1), np.uint32), np.zeros(max(vv.size, 1), np.uint32), np.zeros(max(ev.size, 1), np.uint32)
+    nc, nm = C.c_uint64(0), C.c_uint64(0)
+    lib().orc_filter_int_eq_class(_ptr(vv), _ptr(vc), _ptr(vo), _ptr(mv), _ptr(ev), _ptr(eo), vc.size,
+                                  _ptr(ov), _ptr(om), _ptr(oe), C.byref(nc), C.byref(nm))
+    return ov[: nc.value].copy(), om[: nc.value].copy(), oe[: nm.value].copy()

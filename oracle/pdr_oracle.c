@@ -1008,3 +1008,44 @@ int32_t orc_filter_perfdata(int op, int type, const int32_t *rank_vals, const ui
     free(aggr);
     return rc;
 }
+
+/* ======================================================================= */
+/* tfilter_IntEqClass (src/FilterDefinitions.C:812-902)                     */
+/* ======================================================================= */
+typedef struct { uint32_t val; uint64_t order; uint32_t cnt; uint64_t first; } eq_entry;
+
+static int eq_cmp(const void *a, const void *b)        /* std::map order; arrival order inside a key */
+{
+    const eq_entry *x = (const eq_entry *)a, *y = (const eq_entry *)b;
+    if (x->val != y->val) return x->val < y->val ? -1 : 1;
+    return x->order < y->order ? -1 : (x->order > y->order ? 1 : 0);
+}
+
+int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts, const uint64_t *val_offs,
+                                const uint32_t *memcnts, const uint32_t *mems, const uint64_t *mem_offs,
+                                uint64_t n, uint32_t *out_vals, uint32_t *out_memcnts, uint32_t *out_mems,
+                                uint64_t *nclasses, uint64_t *nmems)
+{
+    uint64_t total = val_offs[n];
+    eq_entry *e = (eq_entry *)malloc((total ? total : 1) * sizeof *e);
+    uint64_t k = 0;
+    for (uint64_t p = 0; p < n; p++) {                     /* :824-849 */
+        uint64_t cur = mem_offs[p];                        /* curClassMemIdx, per packet */
+        for (uint64_t j = 0; j < val_counts[p]; j++) {
+            uint64_t at = val_offs[p] + j;
+            e[k].val = vals[at]; e[k].order = k; e[k].cnt = memcnts[at]; e[k].first = cur;
+            cur += memcnts[at];
+            k++;
+        }
+    }
+    qsort(e, (size_t)total, sizeof *e, eq_cmp);
+    uint64_t nc = 0, nm = 0;
+    for (uint64_t i = 0; i < total; i++) {                 /* :852-875 */
+        if (i == 0 || e[i].val != e[i - 1].val) { out_vals[nc] = e[i].val; out_memcnts[nc] = 0; nc++; }
+        out_memcnts[nc - 1] += e[i].cnt;
+        for (uint32_t m = 0; m < e[i].cnt; m++) out_mems[nm++] = mems[e[i].first + m];
+    }
+    *nclasses = nc; *nmems = nm;
+    free(e);
+    return 1;
+}

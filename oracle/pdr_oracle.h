@@ -191,6 +191,15 @@ int32_t orc_filter_perfdata(int op, int type, const int32_t *rank_vals, const ui
                             const uint64_t *data_counts, const uint64_t *data_offs, uint64_t n,
                             void *out_data, uint64_t out_cap, uint64_t *out_len, int32_t *out_rank);
 
+/*
+ * tfilter_IntEqClass (src/FilterDefinitions.C:812-902): columns of "%aud %aud %aud" packets in,
+ * the three arrays of the output packet out (capacities: as many classes / members as came in).
+ */
+int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts, const uint64_t *val_offs,
+                                const uint32_t *memcnts, const uint32_t *mems, const uint64_t *mem_offs,
+                                uint64_t n, uint32_t *out_vals, uint32_t *out_memcnts, uint32_t *out_mems,
+                                uint64_t *nclasses, uint64_t *nmems);
+
 #ifdef __cplusplus
 }
 #endif

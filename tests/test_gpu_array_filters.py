@@ -102,3 +102,36 @@ def test_perfdata_reference_quirks(codec):
                                                             (np.ones(2, np.uint64), np.ones(2, np.int32)), dd], 2)
     cols = P.tfilter_PerfData(wave, W.TFILTER_MIN).unpack(PERF_FMT[O.DOUBLE_T])
     assert float(W.Codec.to_numpy(cols[2].values).view(np.float64)[0]) == 2.25
+
+
+@pytest.mark.parametrize("n,kmax,vrange,mmax", [(1, 3, 5, 4), (6, 4, 5, 3), (200, 6, 40, 5), (3000, 3, 100000, 4),
+                                                (5000, 2, 7, 2)])
+def test_int_eq_class(codec, n, kmax, vrange, mmax):
+    """tfilter_IntEqClass: classes merged by value (ascending), members in arrival order.
+    Unpinned by reference artefacts; the oracle restates the std::map loops."""
+    kc = (splitmix64(n, n) % np.uint64(kmax + 1)).astype(np.uint64)                    # classes per packet
+    K = int(kc.sum())
+    vals = (splitmix64(n + 1, K) % np.uint64(vrange)).astype(np.uint32)
+    mc = (splitmix64(n + 2, K) % np.uint64(mmax + 1)).astype(np.uint32)                # members per class
+    ko = np.zeros(n + 1, np.int64); np.cumsum(kc, out=ko[1:])
+    ec = np.array([int(mc[ko[i]:ko[i + 1]].sum()) for i in range(n)], np.uint64)       # members per packet
+    mems = (splitmix64(n + 3, int(ec.sum())) % np.uint64(1 << 20)).astype(np.uint32)
+    want = O.filter_int_eq_class((kc, vals), (kc, mc), (ec, mems))
+    wave = P.PacketWave(codec, 3, 100, "%aud %aud %aud", [(kc, vals), (kc, mc), (ec, mems)], n)
+    out = P.tfilter_IntEqClass(wave)
+    assert out is not None and out.n == 1
+    cols = out.unpack("%aud %aud %aud")
+    torch.cuda.synchronize()
+    got = []
+    for c in cols:
+        cnt = int(W.Codec.to_numpy(c.counts).view(np.uint64)[0])
+        got.append(W.Codec.to_numpy(c.values).view(np.uint32)[:cnt])
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert np.all(np.diff(got[0].astype(np.int64)) > 0) and int(got[1].sum()) == got[2].size == int(ec.sum())
+    # and the bytes of the output packet
+    one = [{"type": O.UINT32_ARRAY_T, "counts": np.array([w.size], np.uint64), "offs": np.array([0, w.size], np.uint64),
+            "values": w} for w in want]
+    ref, _, rl = O.wave_encode("%aud %aud %aud", one, 1)
+    assert np.array_equal(W.Codec.to_numpy(out.wire.arena)[: ref.size], ref)
+    assert codec.status() == 0

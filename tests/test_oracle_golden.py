@@ -292,3 +292,9 @@ def test_oracle_matches_its_frozen_vectors(frozen, tmp_path):
     finally:
         shutil.copy(keep, path)
     assert again == frozen
+
+
+def test_int_eq_class_oracle():
+    """src/FilterDefinitions.C:812-902: classes merged by value, members in arrival order."""
+    v, c, m = O.filter_int_eq_class(([2, 2], [5, 7, 5, 3]), ([2, 2], [2, 1, 1, 2]), ([3, 3], [1, 2, 3, 9, 4, 4]))
+    assert v.tolist() == [3, 5, 7] and c.tolist() == [2, 3, 1] and m.tolist() == [4, 4, 1, 2, 9, 3]
