@@ -334,6 +334,15 @@ int32_t mrpdr_wave_filter_stats(mrpdr_ctx *ctx, int32_t type,
 int32_t mrpdr_wave_array_concat(mrpdr_ctx *ctx, const mrpdr_column *in, uint64_t n,
                                 mrpdr_column *out, void *stream);
 
+/* The concatenation tfilter_PerfData performs for TFILTER_ARRAY_CONCAT
+ * (src/FilterDefinitions.C:1000-1008, 1171-1203): as mrpdr_wave_array_concat, but packets whose
+ * mask_counts[i] is 0 (no data) contribute nothing; the kept elements (width bytes each) are
+ * copied into out->values (capacity checked: status bit 0), out->counts[0] / offs[0..1] set.
+ * Called once per field (ranks, nelems, data) with the data field's counts as mask. */
+int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *ctx, const mrpdr_column *in, uint32_t width,
+                                       const uint64_t *mask_counts, uint64_t n,
+                                       mrpdr_column *out, void *stream);
+
 /* tfilter_PerfData with aggregation SUM / MIN / MAX / AVG (src/FilterDefinitions.C:904-1239)
  * over a decoded wave of "%ad %ad %a{uld,ld,lf}" packets: `ranks` is the column of field 0,
  * `data` the column of field 2, type one of MRPDR_UINT64_T / MRPDR_INT64_T / MRPDR_DOUBLE_T.

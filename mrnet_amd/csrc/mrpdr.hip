@@ -1034,6 +1034,56 @@ extern "C" int32_t mrpdr_wave_array_concat(mrpdr_ctx *c, const mrpdr_column *in,
     return 1;
 }
 
+// tfilter_PerfData with TFILTER_ARRAY_CONCAT (src/FilterDefinitions.C:1000-1008, 1171-1203): the
+// arrays of the packets that carry data, back to back; packets without data contribute nothing,
+// not even their rank and nelems arrays.
+__global__ __launch_bounds__(MRPDR_TPB) void k_masked_counts(const uint64_t *counts, const uint64_t *mask_counts,
+                                                             uint64_t n, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i < n) out[i] = mask_counts[i] ? counts[i] : 0;
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_masked_gather(const uint8_t *values, const uint64_t *offs,
+                                                             const uint64_t *kept, const uint64_t *kept_offs,
+                                                             uint64_t n, uint32_t width, uint8_t *out, uint64_t out_cap,
+                                                             uint64_t *out_counts, uint64_t *out_offs, uint32_t *status)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint64_t total = kept_offs[n];
+    const bool fits = total <= out_cap;
+    if (i == 0) {
+        if (!fits) atomicOr(status, 1u);
+        out_counts[0] = fits ? total : 0;
+        out_offs[0] = 0;
+        out_offs[1] = fits ? total : 0;
+    }
+    if (i >= n || !fits) return;
+    const uint8_t *src = values + offs[i] * width;
+    uint8_t *dst = out + kept_offs[i] * width;
+    for (uint64_t b = 0; b < kept[i] * width; b++) dst[b] = src[b];
+}
+
+extern "C" int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *c, const mrpdr_column *in, uint32_t width,
+                                                  const uint64_t *mask_counts, uint64_t n,
+                                                  mrpdr_column *out, void *stream)
+{
+    if (!c || !in || !out || !mask_counts) return fail("mrpdr_wave_array_concat_masked: NULL argument");
+    if (n == 0 || n > c->max_packets) return fail("mrpdr_wave_array_concat_masked: bad n");
+    if (!in->counts || !in->offs || !out->counts || !out->offs || (out->capacity && !out->values))
+        return fail("mrpdr_wave_array_concat_masked: columns need counts, offs and values");
+    if (width != 1 && width != 2 && width != 4 && width != 8) return fail("mrpdr_wave_array_concat_masked: bad width");
+    hipStream_t st = (hipStream_t)stream;
+    k_masked_counts<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in->counts, mask_counts, n, c->pkt_bytes);
+    LAUNCHED("k_masked_counts");
+    if (!run_scan(c, c->pkt_bytes, n, 1, 0, c->pkt_boffs, st)) return 0;
+    k_masked_gather<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>((const uint8_t *)in->values, in->offs, c->pkt_bytes,
+                                                                    c->pkt_boffs, n, width, (uint8_t *)out->values,
+                                                                    out->capacity, out->counts, out->offs, c->status);
+    LAUNCHED("k_masked_gather");
+    return 1;
+}
+
 static inline uint64_t up16(uint64_t v) { return (v + 15) & ~(uint64_t)15; }
 
 extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)

@@ -217,7 +217,7 @@ _PERF_TYPES = {"%ad %ad %auld": W.DataType.UINT64_T, "%ad %ad %ald": W.DataType.
 
 def tfilter_PerfData(ipackets, aggr_id, group=0):
     """Element-wise aggregation of performance-data packets (rank array, nelems array, data array).
-    aggr_id: TFILTER_SUM / MIN / MAX / AVG.  group > 0 declares a two-level tree (nodes of `group`
+    aggr_id: TFILTER_SUM / MIN / MAX / AVG, or TFILTER_ARRAY_CONCAT.  group > 0 declares a two-level tree (nodes of `group`
     children, then one node over their outputs)."""
     fmt, codec, n = ipackets.fmt, ipackets.codec, ipackets.n
     if n == 0 or ipackets.has_Error() or fmt.text not in _PERF_TYPES:
@@ -225,6 +225,12 @@ def tfilter_PerfData(ipackets, aggr_id, group=0):
     cols = ipackets.unpack(fmt.text)
     if ipackets.has_Error():
         return None
+    if aggr_id == W.TFILTER_ARRAY_CONCAT:
+        # ranks, nelems and data of the packets that carry data, back to back
+        mask = cols[2].counts
+        return _from_columns(ipackets, fmt, [codec.array_concat_masked(cols[0], 4, mask, n),
+                                             codec.array_concat_masked(cols[1], 4, mask, n),
+                                             codec.array_concat_masked(cols[2], 8, mask, n)])
     data, out_len, out_rank = codec.filter_perfdata(aggr_id, _PERF_TYPES[fmt.text], cols[0], cols[2], n, group)
     # output packet: ([-total_nranks], [len], data[0:len]); the length lives on the device
     one = torch.ones(1, dtype=torch.int64, device=codec.device)

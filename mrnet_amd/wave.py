@@ -60,6 +60,7 @@ class DataType(enum.IntEnum):
 LITTLEENDIAN, BIGENDIAN = 0, 1
 SCALAR, ARRAY, STRING, STRING_ARRAY = 0, 1, 2, 3
 TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3      # operator codes of the C ABI
+TFILTER_ARRAY_CONCAT = 6          # tfilter_PerfData's concatenating aggregation (host-side code only)
 FILTER_OR, FILTER_AND = 4, 5      # bitwise (not built-in TFILTER_*: the BitsetOr / IntegerPercentiles examples)
 SHAPE_FLAT, SHAPE_TREE = 0, 1
 TREE_FANINS = (4, 2, 2, 2, 2, 2, 2, 4, 0)
@@ -492,6 +493,15 @@ class Codec:
         a, b = col.c_struct(), out.c_struct()
         _check(self._lib.mrpdr_wave_array_concat(self.handle, C.byref(a), n, C.byref(b), _stream()),
                "mrpdr_wave_array_concat")
+        return out
+
+    def array_concat_masked(self, col, width, mask_counts, n):
+        """Concatenation of the arrays of the packets whose mask count is non-zero (a copy)."""
+        cap = max(int(col.capacity), 1)
+        out = Column(self.empty(cap * width, torch.int8), self.empty(1, torch.int64), self.empty(2, torch.int64), cap)
+        a, b = col.c_struct(), out.c_struct()
+        _check(self._lib.mrpdr_wave_array_concat_masked(self.handle, C.byref(a), width, _ptr(mask_counts), n,
+                                                        C.byref(b), _stream()), "mrpdr_wave_array_concat_masked")
         return out
 
     def filter_perfdata(self, op, dtype, ranks, data, n, group=0, out_cap=None):

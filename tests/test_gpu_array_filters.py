@@ -135,3 +135,25 @@ def test_int_eq_class(codec, n, kmax, vrange, mmax):
     ref, _, rl = O.wave_encode("%aud %aud %aud", one, 1)
     assert np.array_equal(W.Codec.to_numpy(out.wire.arena)[: ref.size], ref)
     assert codec.status() == 0
+
+
+def test_perfdata_concat(codec):
+    """TFILTER_ARRAY_CONCAT in tfilter_PerfData (src/FilterDefinitions.C:1000-1008, 1171-1203):
+    packets without data drop out with their rank and nelems arrays."""
+    n = 500
+    dlen = (splitmix64(5, n) % np.uint64(4)).astype(np.uint64)                 # a quarter have no data
+    rlen = (splitmix64(6, n) % np.uint64(3) + np.uint64(1)).astype(np.uint64)
+    ranks = np.arange(int(rlen.sum()), dtype=np.int32)
+    nel = np.arange(int(rlen.sum()), dtype=np.int32) * 3
+    data = random_values(np.float64, int(dlen.sum()), 9)
+    wave = P.PacketWave(codec, 5, 100, "%ad %ad %alf", [(rlen, ranks), (rlen, nel), (dlen, data)], n)
+    out = P.tfilter_PerfData(wave, W.TFILTER_ARRAY_CONCAT)
+    cols = out.unpack("%ad %ad %alf")
+    torch.cuda.synchronize()
+    ro = np.concatenate([[0], np.cumsum(rlen)]).astype(np.int64)
+    keep = np.concatenate([np.arange(ro[i], ro[i + 1]) for i in range(n) if dlen[i]]).astype(np.int64)
+    for c, want, dt in ((cols[0], ranks[keep], np.int32), (cols[1], nel[keep], np.int32), (cols[2], data, np.float64)):
+        cnt = int(W.Codec.to_numpy(c.counts).view(np.uint64)[0])
+        assert cnt == want.size
+        assert np.array_equal(W.Codec.to_numpy(c.values).view(dt)[:cnt].view(np.uint8), want.view(np.uint8))
+    assert codec.status() == 0
