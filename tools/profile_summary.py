@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--rd")
     ap.add_argument("--wr")
-    ap.add_argument("--cmd", default="python3 bench.py --steps 3 --warmup 1 --no-cpu --no-extras")
+    ap.add_argument("--cmd", default="python3 bench.py --steps 5 --warmup 2 --no-cpu --no-extras")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
