@@ -612,6 +612,17 @@ def main():
                 gp, sp = end_to_end_pipelined(codec, a.packets, a.elems)
                 extra["e2e_pipelined_gbps"] = round(gp, 2)
                 extra["e2e_pipelined_ms_per_wave"] = round(sp * 1e3, 3)
+            if (a.packets, a.elems) == (4096, 65536):
+                # the same gibibyte as a 64K-packet wave: 65,536 packets x '%af'[4096]
+                st64 = ArrayWaveStep(codec, 65536, 4096, seed=11)
+                for _ in range(3):
+                    st64.step()
+                torch.cuda.synchronize()
+                st64.verify()
+                sec64 = time_call(st64.step, 20)
+                extra["c3_64k_packets_gbps"] = round(st64.bytes_step / sec64 / 1e9, 1)
+                extra["c3_64k_packets_ms_per_wave"] = round(sec64 * 1e3, 4)
+                del st64
             out["extra"] = extra
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
