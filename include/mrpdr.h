@@ -237,6 +237,21 @@ int32_t mrpdr_wave_decode(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *
                           uint64_t n, int32_t sender_byteorder, mrpdr_column *cols,
                           int32_t *ok, void *stream);
 
+/* Waves whose packets come from senders of both byte orders (a node whose children run on
+ * machines of both kinds).  The reference decodes every packet with the order its own message
+ * carried (src/Packet.C:96,118 -> pdrmem_create, src/pdr_mem.c:433-449).  byteorders: device,
+ * n bytes, as mrpdr_wave_decode_headers writes them; packet i is byte-reversed iff
+ * byteorders[i] != mrpdr_local_byteorder().  Everything else as the calls above. */
+int32_t mrpdr_wave_decode_mixed_begin(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                      uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                      int32_t *ok, uint64_t *totals_host, void *stream);
+int32_t mrpdr_wave_decode_mixed_finish(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                       uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                       void *stream);
+int32_t mrpdr_wave_decode_mixed(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                int32_t *ok, void *stream);
+
 /* ---- packet headers --------------------------------------------------------
  * Packet::pdr_packet_header (src/Packet.C:557-593) for n packets of one format:
  *   u32 stream_id | i32 tag | u32 src_rank | u32 strlen(fmt)+1 | fmt,NUL |

@@ -20,6 +20,7 @@ SYMBOLS = (
     "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
     "mrpdr_wave_sizeof", "mrpdr_wave_encode", "mrpdr_wave_encode_begin", "mrpdr_wave_encode_finish",
     "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
+    "mrpdr_wave_decode_mixed_begin", "mrpdr_wave_decode_mixed_finish", "mrpdr_wave_decode_mixed",
     "mrpdr_header_bytes", "mrpdr_header_bytes_dest", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
     "mrpdr_wave_filter", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
@@ -81,6 +82,10 @@ def load():
                                           C.POINTER(u64), vp]),
         "mrpdr_wave_decode_finish": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp]),
         "mrpdr_wave_decode": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp, vp]),
+        "mrpdr_wave_decode_mixed_begin": (i32, [vp, vp, C.POINTER(Wire), u64, vp, C.POINTER(Column), vp,
+                                                C.POINTER(u64), vp]),
+        "mrpdr_wave_decode_mixed_finish": (i32, [vp, vp, C.POINTER(Wire), u64, vp, C.POINTER(Column), vp]),
+        "mrpdr_wave_decode_mixed": (i32, [vp, vp, C.POINTER(Wire), u64, vp, C.POINTER(Column), vp, vp]),
         "mrpdr_header_bytes": (u64, [vp]),
         "mrpdr_header_bytes_dest": (u64, [vp, u64]),
         "mrpdr_wave_encode_headers": (i32, [vp, vp, u64, u32, vp, i32, vp, u32, vp, vp, u64, vp, vp, u64, vp]),

@@ -40,7 +40,17 @@ struct WireDev {
     const uint64_t *lens;
     uint64_t        stride;
     uint64_t        bytes;
+    const uint8_t  *orders;     // optional: sender byte order of every packet (a wave collected from
+                                // children of both kinds); NULL = one order for the wave
 };
+
+// Whether packet i is byte-reversed on decode: its own order differs from the device's
+// (little-endian, 0) when the wave carries one order per packet, else the wave's setting.
+// pdrmem_create makes the same choice per packet (src/pdr_mem.c:433-449, src/Packet.C:96,118).
+__device__ inline bool pkt_swap(const WireDev &w, uint64_t i, bool uniform)
+{
+    return w.orders ? w.orders[i] != 0 : uniform;
+}
 
 // Length prefix of a variable field: u64 element count for arrays (src/pdr.c:425),
 // u32 strlen+1 for strings (src/pdr.c:295-297).

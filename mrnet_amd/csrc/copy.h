@@ -432,6 +432,29 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy_packets(CopyArgs a, FmtDev f
 }
 
 // ---------------------------------------------------------------------------
+// Waves with one byte order per packet
+// ---------------------------------------------------------------------------
+// A wave collected from children of both byte orders is decoded as if every sender were
+// little-endian (the kernels above, no reversal), then the elements of the packets that came
+// from the other kind are reversed in place: one wavefront per such packet, 128-bit pieces,
+// then the last few elements one per lane.  The extra pass reads and writes only those packets.
+template <int W>
+__global__ __launch_bounds__(MRPDR_TPB) void k_swap_foreign(uint8_t *dense, const uint64_t *offs, const uint8_t *orders,
+                                                            uint64_t n, uint64_t dense_cap)
+{
+    typedef typename UIntOf<W>::type U;
+    const uint64_t s = ((uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (s >= n || !orders[s] || offs[n] * W > dense_cap) return;
+    uint8_t *p = dense + offs[s] * W;
+    const uint64_t len = (offs[s + 1] - offs[s]) * W;
+    const uint64_t whole = len & ~15ull;
+    for (uint64_t b = (uint64_t)lane * COPY_PIECE; b < whole; b += 64 * COPY_PIECE)
+        st16_any<false>(p + b, swap_elems<W>(ld16_any<false>(p + b)));
+    for (uint64_t e = whole + (uint64_t)lane * W; e < len; e += 64 * W) st_u<U>(p + e, bswap_u(ld_u<U>(p + e)));
+}
+
+// ---------------------------------------------------------------------------
 // Calibration: the same streaming loop with no codec logic
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(MRPDR_TPB) void k_plain_copy(uint8_t *dst, const uint8_t *src, uint64_t bytes)

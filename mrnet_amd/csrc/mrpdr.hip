@@ -393,7 +393,7 @@ static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *
     if (!w) return fail("%s: NULL wire", who);
     if (n && !w->base) return fail("%s: NULL arena", who);
     out->base = w->base; out->offsets = w->offsets; out->lens = w->lens;
-    out->stride = w->stride; out->bytes = w->bytes;
+    out->stride = w->stride; out->bytes = w->bytes; out->orders = nullptr;
     if (n && !w->lens && !f->fixed) return fail("%s: lens is required for variable-length formats", who);
     if (n && !w->offsets) {
         if (!f->fixed) return fail("%s: offsets are required for variable-length formats", who);
@@ -689,29 +689,33 @@ extern "C" int32_t mrpdr_wave_encode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
 // ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------
-extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
-                                           uint64_t n, int32_t sender_bo, mrpdr_column *cols,
-                                           int32_t *ok, uint64_t *totals_host, void *stream)
+// orders (optional, device, n bytes): the sender byte order of every packet; sender_bo is then unused.
+// Such a wave takes the one-lane-per-packet walk and the chunk copy (no LDS-staged rows or tiles):
+// waves of both kinds come from trees that span machine types, not from the bandwidth-bound case.
+static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                            uint64_t n, int32_t sender_bo, const uint8_t *orders, mrpdr_column *cols,
+                            int32_t *ok, uint64_t *totals_host, void *stream)
 {
-    if (!check_common("mrpdr_wave_decode_begin", c, f, n)) return 0;
+    if (!check_common(who, c, f, n)) return 0;
     if (sender_bo != MRPDR_LITTLEENDIAN && sender_bo != MRPDR_BIGENDIAN)
-        return fail("mrpdr_wave_decode_begin: bad byte order %d", sender_bo);
+        return fail("%s: bad byte order %d", who, sender_bo);
     ColsDev cd;
     WireDev wd;
-    if (!fill_cols("mrpdr_wave_decode_begin", f, cols, n, false, &cd, false)) return 0;
-    if (!fill_wire("mrpdr_wave_decode_begin", f, wire, n, &wd)) return 0;
+    if (!fill_cols(who, f, cols, n, false, &cd, false)) return 0;
+    if (!fill_wire(who, f, wire, n, &wd)) return 0;
+    wd.orders = orders;
     hipStream_t st = (hipStream_t)stream;
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
     if (totals_host) memset(totals_host, 0, 2 * sizeof(uint64_t) * (size_t)f->dev.nf);
     if (f->dev.nf == 0) return 1;
     if (f->nstrarr) HIP_OK(hipMemsetAsync(c->sa_bytes, 0, MRPDR_MAXF * sizeof(uint64_t), st));
     if (n) {
-        if (rows_path_ok(f, wd)) {
+        if (!orders && rows_path_ok(f, wd)) {
             const size_t lds = ROWS_PER_BLOCK * wd.stride;
             if (swap) k_rows_decode<true><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             LAUNCHED("k_rows_decode");
-        } else if (tile_path_ok(f, wd, n)) {
+        } else if (!orders && tile_path_ok(f, wd, n)) {
             const uint32_t tiles = blocks_for(n, TILE_PKTS);
             if (swap) k_tile_walk<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
             else      k_tile_walk<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
@@ -744,10 +748,10 @@ extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, con
     return 1;
 }
 
-extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
-                                            uint64_t n, int32_t sender_bo, mrpdr_column *cols, void *stream)
+static int32_t decode_finish(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                             uint64_t n, int32_t sender_bo, const uint8_t *orders, mrpdr_column *cols, void *stream)
 {
-    if (!check_common("mrpdr_wave_decode_finish", c, f, n)) return 0;
+    if (!check_common(who, c, f, n)) return 0;
     if (n == 0) {                                   // an empty wave still has sub_offs[0] = 0
         for (int i = 0; cols && i < f->dev.nf; i++)
             if (f->dev.f[i].kind == MRPDR_STRING_ARRAY && cols[i].sub_offs)
@@ -757,11 +761,12 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     if (f->fixed) return 1;
     ColsDev cd;
     WireDev wd;
-    if (!fill_cols("mrpdr_wave_decode_finish", f, cols, n, true, &cd)) return 0;
-    if (!fill_wire("mrpdr_wave_decode_finish", f, wire, n, &wd)) return 0;
+    if (!fill_cols(who, f, cols, n, true, &cd)) return 0;
+    if (!fill_wire(who, f, wire, n, &wd)) return 0;
+    wd.orders = orders;
     hipStream_t st = (hipStream_t)stream;
-    const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
-    if (tile_path_ok(f, wd, n)) {
+    const bool swap = !orders && sender_bo != MRPDR_LITTLEENDIAN;
+    if (!orders && tile_path_ok(f, wd, n)) {
         bool timed;
         if (!perf_begin(c, st, &timed, 0)) return 0;
         const uint32_t tiles = blocks_for(n, TILE_PKTS);
@@ -772,7 +777,7 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     }
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {
-            if (!cd.sub_counts[i]) return fail("mrpdr_wave_decode_finish: field %d (string array) needs sub_counts", i);
+            if (!cd.sub_counts[i]) return fail("%s: field %d (string array) needs sub_counts", who, i);
             if (swap) k_strarr_sizes<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_bytes, c->status);
             else      k_strarr_sizes<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, i, c->pkt_bytes, c->status);
             LAUNCHED("k_strarr_sizes");
@@ -782,17 +787,64 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
             LAUNCHED("k_strarr_decode");
         } else if (f->dev.f[i].kind != MRPDR_SCALAR) {
             if (!copy_field<false>(c, f, wd, cd, i, n, swap, st)) return 0;
+            const uint32_t w = f->dev.f[i].width;
+            if (orders && w > 1 && cd.cap[i]) {        // reverse the elements of the foreign packets in place
+                const uint32_t blocks = blocks_for(n * 64, MRPDR_TPB);
+                uint8_t *v = (uint8_t *)cd.values[i];
+                if (w == 2)      k_swap_foreign<2><<<blocks, MRPDR_TPB, 0, st>>>(v, cd.offs[i], orders, n, cd.cap[i] * w);
+                else if (w == 4) k_swap_foreign<4><<<blocks, MRPDR_TPB, 0, st>>>(v, cd.offs[i], orders, n, cd.cap[i] * w);
+                else             k_swap_foreign<8><<<blocks, MRPDR_TPB, 0, st>>>(v, cd.offs[i], orders, n, cd.cap[i] * w);
+                LAUNCHED("k_swap_foreign");
+            }
         }
     }
     return 1;
+}
+
+extern "C" int32_t mrpdr_wave_decode_begin(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                           uint64_t n, int32_t sender_bo, mrpdr_column *cols,
+                                           int32_t *ok, uint64_t *totals_host, void *stream)
+{
+    return decode_begin("mrpdr_wave_decode_begin", c, f, wire, n, sender_bo, nullptr, cols, ok, totals_host, stream);
+}
+
+extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                            uint64_t n, int32_t sender_bo, mrpdr_column *cols, void *stream)
+{
+    return decode_finish("mrpdr_wave_decode_finish", c, f, wire, n, sender_bo, nullptr, cols, stream);
 }
 
 extern "C" int32_t mrpdr_wave_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
                                      uint64_t n, int32_t sender_bo, mrpdr_column *cols,
                                      int32_t *ok, void *stream)
 {
-    if (!mrpdr_wave_decode_begin(c, f, wire, n, sender_bo, cols, ok, nullptr, stream)) return 0;
-    return mrpdr_wave_decode_finish(c, f, wire, n, sender_bo, cols, stream);
+    if (!decode_begin("mrpdr_wave_decode", c, f, wire, n, sender_bo, nullptr, cols, ok, nullptr, stream)) return 0;
+    return decode_finish("mrpdr_wave_decode", c, f, wire, n, sender_bo, nullptr, cols, stream);
+}
+
+extern "C" int32_t mrpdr_wave_decode_mixed_begin(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                                 uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                                 int32_t *ok, uint64_t *totals_host, void *stream)
+{
+    if (n && !byteorders) return fail("mrpdr_wave_decode_mixed_begin: NULL byteorders");
+    return decode_begin("mrpdr_wave_decode_mixed_begin", c, f, wire, n, 0, n ? byteorders : nullptr, cols, ok,
+                        totals_host, stream);
+}
+
+extern "C" int32_t mrpdr_wave_decode_mixed_finish(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                                  uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                                  void *stream)
+{
+    if (n && !byteorders) return fail("mrpdr_wave_decode_mixed_finish: NULL byteorders");
+    return decode_finish("mrpdr_wave_decode_mixed_finish", c, f, wire, n, 0, n ? byteorders : nullptr, cols, stream);
+}
+
+extern "C" int32_t mrpdr_wave_decode_mixed(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
+                                           uint64_t n, const uint8_t *byteorders, mrpdr_column *cols,
+                                           int32_t *ok, void *stream)
+{
+    if (!mrpdr_wave_decode_mixed_begin(c, f, wire, n, byteorders, cols, ok, nullptr, stream)) return 0;
+    return mrpdr_wave_decode_mixed_finish(c, f, wire, n, byteorders, cols, stream);
 }
 
 // ---------------------------------------------------------------------------

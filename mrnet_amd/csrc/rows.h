@@ -136,8 +136,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev w
 // bytes of all strings of field f over the wave (what the caller sizes values[] with).
 //
 // p points at the packet's first byte (global memory, or a copy of the wire staged in LDS).
-template <bool SWAP>
-__device__ __forceinline__ bool walk_decode_packet(const FmtDev &fmt, const ColsDev &cols, uint64_t i,
+__device__ __forceinline__ bool walk_decode_packet(const bool swap, const FmtDev &fmt, const ColsDev &cols, uint64_t i,
                                                    const uint8_t *p, uint64_t space, bool good,
                                                    uint64_t *sa_bytes, uint64_t *cnt_out = nullptr,
                                                    uint32_t cnt_stride = 0)
@@ -148,13 +147,13 @@ __device__ __forceinline__ bool walk_decode_packet(const FmtDev &fmt, const Cols
         const uint32_t w = fd.width;
         if (fd.kind == MRPDR_SCALAR) {
             uint64_t v = 0;
-            if (good && w <= space) { v = ld_wire_w(p, (int)w, SWAP); p += w; space -= w; }
+            if (good && w <= space) { v = ld_wire_w(p, (int)w, swap); p += w; space -= w; }
             else good = false;
             st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + i * w, (int)w, v);
         } else if (fd.kind == MRPDR_ARRAY) {
             uint64_t cnt = 0;
             if (good && 8 <= space) {
-                cnt = ld_wire<8>(p, SWAP); p += 8; space -= 8;
+                cnt = ld_wire<8>(p, swap); p += 8; space -= 8;
                 const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
                 if (cnt > bound || cnt > space / w) { good = false; cnt = 0; }
                 p += cnt * w; space -= cnt * w;
@@ -165,12 +164,12 @@ __device__ __forceinline__ bool walk_decode_packet(const FmtDev &fmt, const Cols
             // u64 count, then count x [u32 strlen+1 | bytes] (src/Packet.C:794-813)
             uint64_t cnt = 0, bytes = 0;
             if (good && 8 <= space) {
-                cnt = ld_wire<8>(p, SWAP); p += 8; space -= 8;
+                cnt = ld_wire<8>(p, swap); p += 8; space -= 8;
                 const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
                 if (cnt > bound || cnt > space) good = false;
                 for (uint64_t k = 0; good && k < cnt; k++) {
                     if (4 > space) { good = false; break; }
-                    const uint64_t l = ld_wire<4>(p, SWAP); p += 4; space -= 4;
+                    const uint64_t l = ld_wire<4>(p, swap); p += 4; space -= 4;
                     if (l == 0 || l > space) { good = false; break; }
                     p += l; space -= l; bytes += l;
                 }
@@ -182,7 +181,7 @@ __device__ __forceinline__ bool walk_decode_packet(const FmtDev &fmt, const Cols
         } else {    // MRPDR_STRING: u32 strlen+1, then the bytes, NUL included
             uint64_t cnt = 0;
             if (good && 4 <= space) {
-                cnt = ld_wire<4>(p, SWAP); p += 4; space -= 4;
+                cnt = ld_wire<4>(p, swap); p += 4; space -= 4;
                 if (cnt == 0 || cnt > space) { good = false; cnt = 0; }
                 p += cnt; space -= cnt;
             } else good = false;
@@ -202,7 +201,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_walk_decode(FmtDev fmt, WireDev w
     const uint64_t at = pkt_off(wire, i);
     const uint64_t space = pkt_len(wire, fmt, i);
     bool good = at <= wire.bytes && space <= wire.bytes - at;
-    good = walk_decode_packet<SWAP>(fmt, cols, i, wire.base + at, space, good, sa_bytes);
+    good = walk_decode_packet(pkt_swap(wire, i, SWAP), fmt, cols, i, wire.base + at, space, good, sa_bytes);
     if (ok) ok[i] = good ? 1 : 0;
 }
 

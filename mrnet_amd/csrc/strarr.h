@@ -14,19 +14,18 @@
 
 // Wire address of field f's length prefix in packet i.  Only called for packets that decoded
 // through field f, so no bounds checks are repeated here.
-template <bool SWAP>
-__device__ inline const uint8_t *wire_cursor(const FmtDev &fmt, const WireDev &wire, uint64_t i, int f)
+__device__ inline const uint8_t *wire_cursor(const bool swap, const FmtDev &fmt, const WireDev &wire, uint64_t i, int f)
 {
     const uint8_t *p = wire.base + pkt_off(wire, i);
     for (int g = 0; g < f; g++) {
         const FieldDev fd = fmt.f[g];
         if (fd.kind == MRPDR_SCALAR) p += fd.width;
-        else if (fd.kind == MRPDR_ARRAY) p += 8 + ld_wire<8>(p, SWAP) * fd.width;
-        else if (fd.kind == MRPDR_STRING) p += 4 + ld_wire<4>(p, SWAP);
+        else if (fd.kind == MRPDR_ARRAY) p += 8 + ld_wire<8>(p, swap) * fd.width;
+        else if (fd.kind == MRPDR_STRING) p += 4 + ld_wire<4>(p, swap);
         else {
-            const uint64_t c = ld_wire<8>(p, SWAP);
+            const uint64_t c = ld_wire<8>(p, swap);
             p += 8;
-            for (uint64_t k = 0; k < c; k++) p += 4 + ld_wire<4>(p, SWAP);
+            for (uint64_t k = 0; k < c; k++) p += 4 + ld_wire<4>(p, swap);
         }
     }
     return p;
@@ -45,9 +44,10 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_strarr_sizes(FmtDev fmt, WireDev 
         if (i == 0) atomicOr(status, 1u);
     } else if (cols.counts[f][i]) {
         const uint64_t cnt = cols.counts[f][i], first = cols.offs[f][i];
-        const uint8_t *p = wire_cursor<SWAP>(fmt, wire, i, f) + 8;
+        const bool sw = pkt_swap(wire, i, SWAP);
+        const uint8_t *p = wire_cursor(sw, fmt, wire, i, f) + 8;
         for (uint64_t k = 0; k < cnt; k++) {
-            const uint64_t l = ld_wire<4>(p, SWAP);
+            const uint64_t l = ld_wire<4>(p, sw);
             cols.sub_counts[f][first + k] = l;
             p += 4 + l;
             bytes += l;
@@ -73,11 +73,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_strarr_decode(FmtDev fmt, WireDev
     // also the next packet's first entry (same value), and sub_offs[total] from the last packet
     if (lane == 0) cols.sub_offs[f][first + cnt] = pkt_boffs[i + 1];
     if (!cnt) return;
-    const uint8_t *p = wire_cursor<SWAP>(fmt, wire, i, f) + 8;
+    const bool sw = pkt_swap(wire, i, SWAP);
+    const uint8_t *p = wire_cursor(sw, fmt, wire, i, f) + 8;
     uint8_t *values = reinterpret_cast<uint8_t *>(cols.values[f]);
     uint64_t run = pkt_boffs[i];
     for (uint64_t k = 0; k < cnt; k++) {
-        const uint64_t l = ld_wire<4>(p, SWAP);
+        const uint64_t l = ld_wire<4>(p, sw);
         if (lane == 0) cols.sub_offs[f][first + k] = run;
         for (uint64_t b = lane; b < l; b += 64) values[run + b] = p[4 + b];
         p += 4 + l;

@@ -277,13 +277,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv
     if (t < np) {
         const uint64_t at = m.start[t], space = m.end[t] - at;
         if (staged) {
-            good = walk_decode_packet<SWAP>(fmt, cols, p0 + t, tile_at<true>(img, wire.base, lo, mis, at), space, true,
+            good = walk_decode_packet(SWAP, fmt, cols, p0 + t, tile_at<true>(img, wire.base, lo, mis, at), space, true,
                                             nullptr, &m.seg[0][t], TILE_PKTS + 1);
         } else {
             // same checks as the generic walker: the packet must lie inside the arena
             const uint64_t len = wire.lens[p0 + t];
             good = at <= wire.bytes && len <= wire.bytes - at;
-            good = walk_decode_packet<SWAP>(fmt, cols, p0 + t, wire.base + at, len, good, nullptr,
+            good = walk_decode_packet(SWAP, fmt, cols, p0 + t, wire.base + at, len, good, nullptr,
                                             &m.seg[0][t], TILE_PKTS + 1);
         }
         if (ok) ok[p0 + t] = good ? 1 : 0;

@@ -66,8 +66,10 @@ class PacketWave:
             self.tag = int(h["tag"][0].item())
             bo = h["byteorder"]
             self.byteorder = int(bo[0].item())
-            if not bool(h["ok"].all()) or not bool((bo == bo[0]).all()):
-                self._error = True          # foreign format or mixed byte orders in one wave
+            if not bool((bo == bo[0]).all()):
+                self.byteorder = bo         # children of both kinds: every packet keeps its own order
+            if not bool(h["ok"].all()):
+                self._error = True          # a packet of another format in the wave
         else:
             self.stream_id, self.tag, self.byteorder = 0xFFFFFFFF, -1, W.LITTLEENDIAN
         return self
@@ -158,7 +160,7 @@ def _run_filter(op, ipackets, shape):
     elif fmt.text not in _SCALAR_FORMATS:
         return None             # the reference logs "invalid packet type" and emits nothing
     wire = ipackets.wire
-    if wire.offsets is None:
+    if wire.offsets is None and not isinstance(ipackets.byteorder, torch.Tensor):
         res, ok = codec.filter_wire(op, fmt, wire, ipackets.byteorder, shape)      # fused decode
     else:
         cols = ipackets.unpack(fmt.text)
@@ -269,7 +271,8 @@ def IntegerPercentiles(ipackets, state=None, shape=W.SHAPE_TREE):
     min fr_range_max); returns (output PacketWave, new state).  Integer OR / max / min do not
     depend on the order, so the state simply is one more input of each fold."""
     codec, fmt, n = ipackets.codec, ipackets.fmt, ipackets.n
-    if fmt.text != "%uld %ud %ud" or n == 0 or ipackets.has_Error() or ipackets.wire.offsets is not None:
+    if fmt.text != "%uld %ud %ud" or n == 0 or ipackets.has_Error() or ipackets.wire.offsets is not None \
+            or isinstance(ipackets.byteorder, torch.Tensor):
         return None, state
     if state is None:
         state = torch.zeros(16, dtype=torch.uint8, device=codec.device)

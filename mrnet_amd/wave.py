@@ -315,27 +315,36 @@ class Codec:
         return wire
 
     # ---- decode ---------------------------------------------------------------------
+    # sender_bo below: LITTLEENDIAN / BIGENDIAN for the whole wave, or a uint8 device tensor with
+    # the byte order of every packet (as decode_headers returns it) for a wave of both kinds.
+    def _decode_fn(self, name, sender_bo):
+        if isinstance(sender_bo, torch.Tensor):
+            if sender_bo.dtype != torch.uint8 or not sender_bo.is_contiguous():
+                raise ValueError("per-packet byte orders must be a contiguous uint8 tensor")
+            return getattr(self._lib, name.replace("decode", "decode_mixed")), _ptr(sender_bo)
+        return getattr(self._lib, name), sender_bo
+
     def decode_begin(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN, want_totals=True):
         w = wire.c_struct()
         totals = (C.c_uint64 * max(1, 2 * len(fmt)))()
         carr = _c_columns(cols)
-        r = self._lib.mrpdr_wave_decode_begin(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
-                                              carr, _ptr(ok), totals if want_totals else None, _stream())
-        _check(r, "mrpdr_wave_decode_begin")
+        fn, bo = self._decode_fn("mrpdr_wave_decode_begin", sender_bo)
+        _check(fn(self.handle, fmt.handle, C.byref(w), wire.n, bo, carr, _ptr(ok),
+                  totals if want_totals else None, _stream()), "mrpdr_wave_decode_begin")
         return [totals[i] for i in range(2 * len(fmt))] if want_totals else None
 
     def decode_finish(self, fmt, wire, cols, sender_bo=LITTLEENDIAN):
         w = wire.c_struct()
-        r = self._lib.mrpdr_wave_decode_finish(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
-                                               _c_columns(cols), _stream())
-        _check(r, "mrpdr_wave_decode_finish")
+        fn, bo = self._decode_fn("mrpdr_wave_decode_finish", sender_bo)
+        _check(fn(self.handle, fmt.handle, C.byref(w), wire.n, bo, _c_columns(cols), _stream()),
+               "mrpdr_wave_decode_finish")
 
     def decode_into(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN):
         """Columns already sized by the caller: no host synchronisation."""
         w = wire.c_struct()
-        r = self._lib.mrpdr_wave_decode(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
-                                        _c_columns(cols), _ptr(ok), _stream())
-        _check(r, "mrpdr_wave_decode")
+        fn, bo = self._decode_fn("mrpdr_wave_decode", sender_bo)
+        _check(fn(self.handle, fmt.handle, C.byref(w), wire.n, bo, _c_columns(cols), _ptr(ok), _stream()),
+               "mrpdr_wave_decode")
 
     def decode(self, fmt, wire, sender_bo=LITTLEENDIAN):
         """Decode a wave; returns (columns, ok).  Array columns are allocated from the

@@ -80,6 +80,8 @@ def lib():
         L.orc_wave_decode.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, C.c_int,
                                       C.POINTER(_Column), vp]
         L.orc_wave_decode.restype = C.c_uint64
+        L.orc_wave_decode_orders.argtypes = [C.c_char_p, vp, vp, vp, C.c_uint64, vp, C.POINTER(_Column), vp]
+        L.orc_wave_decode_orders.restype = C.c_uint64
         L.orc_header_encode.argtypes = [C.c_uint32, C.c_int32, C.c_uint32, C.c_char_p, vp,
                                         C.c_uint64, vp, C.c_uint64]
         L.orc_header_encode.restype = C.c_uint64
@@ -186,7 +188,8 @@ def wave_encode(fmt, cols, n, align=1, phase=0):
 
 
 def wave_decode(fmt, arena, offsets, lens, sender_bo=LITTLE):
-    """Returns (cols, ok i32[n]).  Columns are trimmed to the decoded totals."""
+    """Returns (cols, ok i32[n]).  Columns are trimmed to the decoded totals.
+    sender_bo: LITTLE / BIG for the wave, or a uint8 array with every packet's own order."""
     types = fmt_types(fmt)
     n = len(lens)
     arena = np.ascontiguousarray(arena, dtype=np.uint8)
@@ -210,8 +213,14 @@ def wave_decode(fmt, arena, offsets, lens, sender_bo=LITTLE):
         cols.append(c)
     ok = np.zeros(n, dtype=np.int32)
     keep = []
-    lib().orc_wave_decode(fmt.encode(), _ptr(arena), _ptr(offsets), _ptr(lens), n, sender_bo,
-                          _c_columns(cols, keep), _ptr(ok))
+    if isinstance(sender_bo, np.ndarray):           # one byte order per packet
+        orders = np.ascontiguousarray(sender_bo, dtype=np.uint8)
+        assert orders.size == n
+        lib().orc_wave_decode_orders(fmt.encode(), _ptr(arena), _ptr(offsets), _ptr(lens), n, _ptr(orders),
+                                     _c_columns(cols, keep), _ptr(ok))
+    else:
+        lib().orc_wave_decode(fmt.encode(), _ptr(arena), _ptr(offsets), _ptr(lens), n, sender_bo,
+                              _c_columns(cols, keep), _ptr(ok))
     for c in cols:
         k = type_kind(c["type"])
         if k in (1, 2):

@@ -605,9 +605,11 @@ int32_t orc_wave_encode(const char *fmt, const orc_column *cols, uint64_t n,
     return 1;
 }
 
-uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *offsets,
-                         const uint64_t *lens, uint64_t n, int sender_bo,
-                         orc_column *cols, int32_t *ok)
+/* orders (optional): the byte order each packet's message announced; every packet is decoded
+ * with its own (src/Packet.C:118 passes the packet's _byteorder to pdrmem_create). */
+static uint64_t wave_decode(const char *fmt, const char *arena, const uint64_t *offsets,
+                            const uint64_t *lens, uint64_t n, int sender_bo, const uint8_t *orders,
+                            orc_column *cols, int32_t *ok)
 {                                                                   /* src/Packet.C:106-133 per packet */
     int types[64];
     int nf = orc_fmt_types(fmt, types, 64);
@@ -624,7 +626,7 @@ uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *off
         int32_t rc = 1;
         if (lens[i] != 0) {
             orc_stream s;
-            orc_mem_create(&s, (char *)arena + offsets[i], lens[i], ORC_DECODE, sender_bo);
+            orc_mem_create(&s, (char *)arena + offsets[i], lens[i], ORC_DECODE, orders ? orders[i] : sender_bo);
             rc = orc_packet_data(&s, &pkt);
         } else if (nf != 0) {
             rc = 0;   /* a non-empty format cannot have an empty body */
@@ -673,6 +675,20 @@ uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *off
         packet_clear(&pkt);
     }
     return good;
+}
+
+uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *offsets,
+                         const uint64_t *lens, uint64_t n, int sender_bo,
+                         orc_column *cols, int32_t *ok)
+{
+    return wave_decode(fmt, arena, offsets, lens, n, sender_bo, NULL, cols, ok);
+}
+
+uint64_t orc_wave_decode_orders(const char *fmt, const char *arena, const uint64_t *offsets,
+                                const uint64_t *lens, uint64_t n, const uint8_t *orders,
+                                orc_column *cols, int32_t *ok)
+{
+    return wave_decode(fmt, arena, offsets, lens, n, 0, orders, cols, ok);
 }
 
 /* ======================================================================= */

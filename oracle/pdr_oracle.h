@@ -146,6 +146,10 @@ int32_t orc_wave_encode(const char *fmt, const orc_column *cols, uint64_t n,
 uint64_t orc_wave_decode(const char *fmt, const char *arena, const uint64_t *offsets,
                          const uint64_t *lens, uint64_t n, int sender_bo,
                          orc_column *cols, int32_t *ok);
+/* The same with one byte order per packet (orders[i], as each packet's message announced it). */
+uint64_t orc_wave_decode_orders(const char *fmt, const char *arena, const uint64_t *offsets,
+                                const uint64_t *lens, uint64_t n, const uint8_t *orders,
+                                orc_column *cols, int32_t *ok);
 
 /* ---- message framing (src/Message.C:201-335 send, :48-199 recv) -------------------- */
 /* Gathers n (header, buffer) pairs into one message the way Message::send hands them to writev.

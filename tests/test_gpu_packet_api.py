@@ -139,3 +139,50 @@ def test_receive_side_errors(codec):
                                                   (np.zeros(n, np.uint64), np.zeros(0, np.int64))])
     bad = PacketWave.from_buffers(codec, fmt, n, other.get_Header(), other.get_HeaderLen(), sent.get_Buffer())
     assert bad.has_Error()
+
+
+def test_wave_from_children_of_both_byte_orders(codec):
+    """Packets of one wave keep the byte order their own message announced (src/Packet.C:96,118):
+    a receive-side wave whose odd packets came from big-endian senders unpacks to the same values,
+    and the scalar filters fold it."""
+    from wavegen import O, to_sender_order
+    fmt = "%d %ad"
+    n = 40
+    vals = np.arange(n, dtype=np.int32) * 7 - 50
+    arr = np.arange(3 * n, dtype=np.int32)
+    sent = PacketWave(codec, 9, 101, fmt, [vals, (np.full(n, 3, np.uint64), arr)])
+    hl = sent.get_HeaderLen()
+    hdrs = W.Codec.to_numpy(sent.get_Header()).reshape(n, hl).copy()
+    buf = sent.get_Buffer()
+    arena = W.Codec.to_numpy(buf.arena).copy()
+    offs = W.Codec.to_numpy(buf.offsets).view(np.uint64)
+    lens = W.Codec.to_numpy(buf.lens).view(np.uint64)
+    be = to_sender_order(fmt, arena, offs, lens)
+    flen = len(fmt) + 1
+    for i in range(1, n, 2):
+        arena[int(offs[i]):int(offs[i] + lens[i])] = be[int(offs[i]):int(offs[i] + lens[i])]
+        for a in (0, 4, 8, 12):
+            hdrs[i, a:a + 4] = hdrs[i, a:a + 4][::-1].copy()
+        hdrs[i, 16 + flen:24 + flen] = hdrs[i, 16 + flen:24 + flen][::-1].copy()
+        hdrs[i, hl - 1] = W.BIGENDIAN
+    wire = W.WireWave(codec.to_device(arena), n, buf.offsets, buf.lens, 0)
+    got = PacketWave.from_buffers(codec, fmt, n, codec.to_device(hdrs.reshape(-1)), hl, wire)
+    assert not got.has_Error() and got.get_StreamId() == 9 and got.get_Tag() == 101
+    cols = got.unpack(fmt)
+    assert cols != -1 and not got.has_Error()
+    assert np.array_equal(W.Codec.to_numpy(cols[0].values).view(np.int32), vals)
+    assert np.array_equal(W.Codec.to_numpy(cols[1].values).view(np.int32)[:3 * n], arr)
+    # a scalar wave of both orders through tfilter_Sum
+    s = PacketWave(codec, 9, 101, "%d", [vals])
+    h1 = W.Codec.to_numpy(s.get_Header()).reshape(n, s.get_HeaderLen()).copy()
+    a1 = W.Codec.to_numpy(s.get_Buffer().arena).copy()[:4 * n].reshape(n, 4)
+    for i in range(1, n, 2):
+        a1[i] = a1[i][::-1].copy()
+        for a in (0, 4, 8, 12):
+            h1[i, a:a + 4] = h1[i, a:a + 4][::-1].copy()
+        h1[i, 16 + 3:24 + 3] = h1[i, 16 + 3:24 + 3][::-1].copy()
+        h1[i, -1] = W.BIGENDIAN
+    w1 = W.WireWave(codec.to_device(a1.reshape(-1)), n, None, None, 4)
+    g1 = PacketWave.from_buffers(codec, "%d", n, codec.to_device(h1.reshape(-1)), s.get_HeaderLen(), w1)
+    out = tfilter_Sum(g1)
+    assert out is not None and int(W.Codec.to_numpy(out.unpack("%d")[0].values).view(np.int32)[0]) == int(vals.sum())

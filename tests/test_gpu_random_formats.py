@@ -89,3 +89,56 @@ def test_random_truncation(codec, seed):
     dcols, ok = codec.decode(fmt, wire, bo)
     assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
     assert columns_equal(host_cols(fmt, dcols, n), ref_cols), fmt_s
+
+
+def mixed_arena(fmt_s, arena, offs, lens, orders):
+    """Every packet as its own sender wrote it: orders[i] != 0 = big-endian."""
+    be = to_sender_order(fmt_s, arena, offs, lens)
+    out = arena.copy()
+    for i in np.nonzero(orders)[0]:
+        a, b = int(offs[i]), int(offs[i]) + int(lens[i])
+        out[a:b] = be[a:b]
+    return out
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_mixed_byte_orders(codec, seed):
+    """A wave collected from senders of both byte orders (src/Packet.C:96,118: every packet is
+    decoded with the order its message announced), whole and truncated packets."""
+    fmt_s, n, max_count, align, phase = draw(9000 + seed)
+    n = max(n, 2)
+    if n * max_count > 200000:
+        max_count = 40
+    ocols = make_wave(fmt_s, n, seed, max_count=max_count)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n, align=align, phase=phase)
+    orders = (splitmix64(31 + seed, n) % np.uint64(3) == 0).astype(np.uint8)     # a third are foreign
+    if seed % 5 == 0:
+        orders[:] = 1
+    src = mixed_arena(fmt_s, arena, offs, lens, orders)
+    cut = lens
+    if seed % 2:
+        r = splitmix64(78 + seed, n)
+        cut = np.where(r % np.uint64(3) == 0, lens, r % (lens + np.uint64(1))).astype(np.uint64)
+    ref_cols, ref_ok = O.wave_decode(fmt_s, src, offs, cut, orders)
+    if cut is lens:
+        assert columns_equal(ref_cols, ocols) and bool(ref_ok.all())
+    fmt = W.Format(fmt_s)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, cut), codec.to_device(orders))
+    assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
+    assert columns_equal(host_cols(fmt, dcols, n), ref_cols), (fmt_s, n)
+    assert codec.status() == 0
+
+
+def test_mixed_orders_large_arrays(codec):
+    """Arrays long enough for the chunk kernel, then the in-place reversal of the foreign packets."""
+    n, m = 96, 40000
+    fmt_s = "%d %alf %ahd"
+    counts = {1: np.full(n, m, dtype=np.uint64), 2: (splitmix64(4, n) % np.uint64(3000)).astype(np.uint64)}
+    ocols = make_wave(fmt_s, n, 12, counts=counts)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    orders = (np.arange(n) % 2).astype(np.uint8)
+    src = mixed_arena(fmt_s, arena, offs, lens, orders)
+    fmt = W.Format(fmt_s)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, lens), codec.to_device(orders))
+    assert bool(ok.all())
+    assert columns_equal(host_cols(fmt, dcols, n), ocols)

@@ -298,3 +298,23 @@ def test_int_eq_class_oracle():
     """src/FilterDefinitions.C:812-902: classes merged by value, members in arrival order."""
     v, c, m = O.filter_int_eq_class(([2, 2], [5, 7, 5, 3]), ([2, 2], [2, 1, 1, 2]), ([3, 3], [1, 2, 3, 9, 4, 4]))
     assert v.tolist() == [3, 5, 7] and c.tolist() == [2, 3, 1] and m.tolist() == [4, 4, 1, 2, 9, 3]
+
+
+def test_wave_decode_with_one_order_per_packet():
+    """Every packet decoded with the order its message announced (src/Packet.C:96,118): a wave
+    whose packets alternate between the two orders decodes to the columns it was built from."""
+    from wavegen import make_wave, to_sender_order, columns_equal
+    fmt = "%hd %s %auld %as %f"
+    n = 37
+    cols = make_wave(fmt, n, 5, max_count=9)
+    arena, offs, lens = O.wave_encode(fmt, cols, n)
+    be = to_sender_order(fmt, arena, offs, lens)
+    orders = (np.arange(n) % 2).astype(np.uint8)
+    src = arena.copy()
+    for i in np.nonzero(orders)[0]:
+        src[int(offs[i]):int(offs[i] + lens[i])] = be[int(offs[i]):int(offs[i] + lens[i])]
+    got, ok = O.wave_decode(fmt, src, offs, lens, orders)
+    assert bool(ok.all()) and columns_equal(got, cols)
+    # the wrong order for the foreign half: length prefixes read reversed, those packets fail
+    _, ok_le = O.wave_decode(fmt, src, offs, lens, O.LITTLE)
+    assert np.array_equal(ok_le != 0, orders == 0)
