@@ -13,6 +13,7 @@
 //                                                    src/Message.C:288-292)
 //   tfilter_Sum / Max / Min / Avg                   one output packet with the stream id and tag
 //                                                    of the first input (src/FilterDefinitions.C:151-221)
+//   tfilter_ArrayConcat / PerfData / IntEqClass     the array filters (src/FilterDefinitions.C:649-1239)
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -412,6 +413,8 @@ class PacketWave {
     int32_t byteorder() const { return byteorder_; }
     const std::vector<mrpdr_column> &columns() { decode_pdr_data(); return cols_; }
     WaveContext &context() const { return wc_; }
+    // elements of field f over the whole wave (strings of a string array)
+    uint64_t total(int f) { decode_pdr_data(); return totals_[f]; }
 
  private:
     void alloc_column_structs()
@@ -506,8 +509,11 @@ class PacketWave {
         d_ok.download(okh.data(), 4 * n_, wc_.stream);
         wc_.sync();
         if (n_) { stream_id_ = sid[0]; tag_ = tag[0]; byteorder_ = bo[0]; }
-        for (uint64_t i = 0; i < n_; i++)
-            if (!okh[i] || bo[i] != bo[0]) error_ = true;     // foreign format or mixed byte orders
+        for (uint64_t i = 0; i < n_; i++) {
+            if (!okh[i]) error_ = true;                       // a packet of another format
+            if (bo[i] != bo[0]) mixed_ = true;                // children of both kinds: each packet keeps its order
+        }
+        if (mixed_) d_orders_.upload(bo.data(), n_, wc_.stream), wc_.sync();
         wire_ = mrpdr_wire{ d_arena_.ptr<uint8_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, arena_bytes_ };
     }
 
@@ -531,8 +537,12 @@ class PacketWave {
         }
         DeviceBuffer d_ok;
         d_ok.resize(4 * n_);
-        if (!mrpdr_wave_decode_begin(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), d_ok.ptr<int32_t>(),
-                                     totals_.data(), wc_.stream)) throw PdrError("mrpdr_wave_decode_begin");
+        const int began = mixed_
+            ? mrpdr_wave_decode_mixed_begin(wc_.ctx, fmt_, &wire_, n_, d_orders_.ptr<uint8_t>(), cols_.data(),
+                                            d_ok.ptr<int32_t>(), totals_.data(), wc_.stream)
+            : mrpdr_wave_decode_begin(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), d_ok.ptr<int32_t>(),
+                                      totals_.data(), wc_.stream);
+        if (!began) throw PdrError("mrpdr_wave_decode_begin");
         for (int f = 0; f < nf; f++)
             if (mrpdr_fmt_field_kind(fmt_, f) != MRPDR_SCALAR) {
                 const bool sa = mrpdr_fmt_field_kind(fmt_, f) == MRPDR_STRING_ARRAY;
@@ -548,8 +558,10 @@ class PacketWave {
                     cols_[f].sub_capacity = totals_[f];
                 }
             }
-        if (!mrpdr_wave_decode_finish(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), wc_.stream))
-            throw PdrError("mrpdr_wave_decode_finish");
+        const int finished = mixed_
+            ? mrpdr_wave_decode_mixed_finish(wc_.ctx, fmt_, &wire_, n_, d_orders_.ptr<uint8_t>(), cols_.data(), wc_.stream)
+            : mrpdr_wave_decode_finish(wc_.ctx, fmt_, &wire_, n_, byteorder_, cols_.data(), wc_.stream);
+        if (!finished) throw PdrError("mrpdr_wave_decode_finish");
         ok_.resize(n_);
         d_ok.download(ok_.data(), 4 * n_, wc_.stream);
         wc_.sync();
@@ -565,9 +577,10 @@ class PacketWave {
     int32_t tag_;
     int32_t byteorder_;
     bool decoded_, error_, have_hdrs_;
+    bool mixed_ = false;            // the wave holds packets of both sender byte orders
     unsigned hdr_len_ = 0;
     uint64_t arena_bytes_ = 0;
-    DeviceBuffer d_hdrs_, d_arena_, d_offs_, d_lens_;
+    DeviceBuffer d_hdrs_, d_arena_, d_offs_, d_lens_, d_orders_;
     std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_, d_subc_, d_subo_;
     std::vector<mrpdr_column> cols_;
     std::vector<uint64_t> totals_;
@@ -605,5 +618,145 @@ inline int tfilter_Sum(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TR
 inline int tfilter_Max(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MAX, in, shape, r, nullptr); }
 inline int tfilter_Min(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MIN, in, shape, r, nullptr); }
 inline int tfilter_Avg(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_AVG, in, shape, r, nullptr); }
+
+
+// ---- built-in array filters ------------------------------------------------------------------
+// Each returns 0 and the fields of the ONE output packet as host columns (what unpack of that
+// packet hands out), or -1 when the filter emits nothing.
+
+// The column of a one-packet wave, brought to the host.
+inline void download_single(WaveContext &wc, const mrpdr_column &c, int width, bool string_array, HostColumn &out)
+{
+    out = HostColumn();
+    out.counts.resize(1);
+    hip_check(hipMemcpyAsync(out.counts.data(), c.counts, 8, hipMemcpyDeviceToHost, wc.stream), "hipMemcpyAsync D2H");
+    wc.sync();
+    uint64_t bytes = out.counts[0] * (uint64_t)width;
+    if (string_array) {
+        out.sub_counts.resize(out.counts[0]);
+        if (out.counts[0]) {
+            hip_check(hipMemcpyAsync(out.sub_counts.data(), c.sub_counts, 8 * out.counts[0], hipMemcpyDeviceToHost, wc.stream),
+                      "hipMemcpyAsync D2H");
+            wc.sync();
+        }
+        bytes = 0;
+        for (uint64_t l : out.sub_counts) bytes += l;
+    }
+    out.values.resize(bytes);
+    if (bytes) hip_check(hipMemcpyAsync(out.values.data(), c.values, bytes, hipMemcpyDeviceToHost, wc.stream), "hipMemcpyAsync D2H");
+    wc.sync();
+}
+
+// tfilter_ArrayConcat (src/FilterDefinitions.C:649-810): every input array in packet order.
+inline int tfilter_ArrayConcat(PacketWave &in, HostColumn &out)
+{
+    const mrpdr_fmt *f = in.format();
+    if (in.size() == 0 || in.has_Error() || mrpdr_fmt_nfields(f) != 1) return -1;
+    const int kind = mrpdr_fmt_field_kind(f, 0);
+    if (kind != MRPDR_ARRAY && kind != MRPDR_STRING_ARRAY) return -1;   // "invalid packet type", :764-768
+    const std::vector<mrpdr_column> &cols = in.columns();
+    if (in.has_Error()) return -1;
+    WaveContext &wc = in.context();
+    DeviceBuffer d_cnt, d_offs;
+    d_cnt.resize(8); d_offs.resize(16);
+    mrpdr_column o = cols[0];                       // the values column of the wave IS the output array
+    o.counts = d_cnt.ptr<uint64_t>();
+    o.offs = d_offs.ptr<uint64_t>();
+    if (!mrpdr_wave_array_concat(wc.ctx, &cols[0], in.size(), &o, wc.stream)) throw PdrError("mrpdr_wave_array_concat");
+    download_single(wc, o, mrpdr_fmt_field_width(f, 0), kind == MRPDR_STRING_ARRAY, out);
+    return 0;
+}
+
+// tfilter_PerfData's concatenating aggregation takes this id beside MRPDR_SUM/MIN/MAX/AVG
+// (the reference compares aggr_id with the registered id of TFILTER_ARRAY_CONCAT,
+// src/FilterDefinitions.C:1000).
+enum { PERFDATA_ARRAY_CONCAT = 6 };
+
+// tfilter_PerfData (src/FilterDefinitions.C:904-1239) over "%ad %ad %a{uld,ld,lf}" packets:
+// out = (rank array, nelems array, data array) of the output packet.  group > 0 declares a
+// two-level tree (nodes of `group` children, then one node over their outputs).
+inline int tfilter_PerfData(PacketWave &in, int aggr_id, std::vector<HostColumn> &out, uint64_t group = 0)
+{
+    const char *fmt = in.get_FormatString();
+    int type;
+    if (!strcmp(fmt, "%ad %ad %auld")) type = MRPDR_UINT64_T;
+    else if (!strcmp(fmt, "%ad %ad %ald")) type = MRPDR_INT64_T;
+    else if (!strcmp(fmt, "%ad %ad %alf")) type = MRPDR_DOUBLE_T;
+    else return -1;
+    const uint64_t n = in.size();
+    if (n == 0 || in.has_Error()) return -1;
+    const std::vector<mrpdr_column> &cols = in.columns();
+    if (in.has_Error()) return -1;
+    WaveContext &wc = in.context();
+    out.assign(3, HostColumn());
+    if (aggr_id == PERFDATA_ARRAY_CONCAT) {
+        const uint32_t widths[3] = { 4, 4, 8 };
+        for (int f = 0; f < 3; f++) {
+            DeviceBuffer d_val, d_cnt, d_offs;
+            const uint64_t cap = in.total(f) ? in.total(f) : 1;
+            d_val.resize(cap * widths[f]); d_cnt.resize(8); d_offs.resize(16);
+            mrpdr_column o = mrpdr_column();
+            o.values = d_val.ptr<void>(); o.counts = d_cnt.ptr<uint64_t>(); o.offs = d_offs.ptr<uint64_t>();
+            o.capacity = cap;
+            if (!mrpdr_wave_array_concat_masked(wc.ctx, &cols[f], widths[f], cols[2].counts, n, &o, wc.stream))
+                throw PdrError("mrpdr_wave_array_concat_masked");
+            download_single(wc, o, (int)widths[f], false, out[f]);
+        }
+        return 0;
+    }
+    if (aggr_id != MRPDR_SUM && aggr_id != MRPDR_MIN && aggr_id != MRPDR_MAX && aggr_id != MRPDR_AVG) return -1;
+    std::vector<uint64_t> lens(n);
+    hip_check(hipMemcpyAsync(lens.data(), cols[2].counts, 8 * n, hipMemcpyDeviceToHost, wc.stream), "hipMemcpyAsync D2H");
+    wc.sync();
+    uint64_t cap = 0;
+    for (uint64_t l : lens) cap = l > cap ? l : cap;
+    DeviceBuffer d_out, d_len, d_rank, d_scratch;
+    d_out.resize(8 * (cap ? cap : 1)); d_len.resize(8); d_rank.resize(4);
+    const uint64_t need = mrpdr_perfdata_scratch_bytes(n, group, cap);
+    if (need) d_scratch.resize(need);
+    if (!mrpdr_wave_perfdata(wc.ctx, aggr_id, type, &cols[0], &cols[2], n, group, d_out.ptr<void>(), cap,
+                             d_len.ptr<uint64_t>(), d_rank.ptr<int32_t>(), need ? d_scratch.ptr<void>() : nullptr, need,
+                             wc.stream)) throw PdrError("mrpdr_wave_perfdata");
+    uint64_t len = 0;
+    int32_t rank = 0;
+    d_len.download(&len, 8, wc.stream);
+    d_rank.download(&rank, 4, wc.stream);
+    wc.sync();
+    const int32_t nelems = (int32_t)len;
+    out[0].counts.assign(1, 1); out[0].values.assign((const uint8_t *)&rank, (const uint8_t *)(&rank + 1));
+    out[1].counts.assign(1, 1); out[1].values.assign((const uint8_t *)&nelems, (const uint8_t *)(&nelems + 1));
+    out[2].counts.assign(1, len);
+    out[2].values.resize(8 * len);
+    d_out.download(out[2].values.data(), 8 * len, wc.stream);
+    wc.sync();
+    return 0;
+}
+
+// tfilter_IntEqClass (src/FilterDefinitions.C:812-902) over "%aud %aud %aud" packets: the
+// classes of all inputs merged by value.  out = (values, members per class, members).
+inline int tfilter_IntEqClass(PacketWave &in, std::vector<HostColumn> &out)
+{
+    if (strcmp(in.get_FormatString(), "%aud %aud %aud") != 0 || in.size() == 0 || in.has_Error()) return -1;
+    const std::vector<mrpdr_column> &cols = in.columns();
+    if (in.has_Error()) return -1;
+    WaveContext &wc = in.context();
+    const uint64_t kcap = in.total(0) ? in.total(0) : 1, mcap = in.total(2) ? in.total(2) : 1;
+    const uint64_t caps[3] = { kcap, kcap, mcap };
+    DeviceBuffer d_val[3], d_cnt[3], d_offs[3], d_scratch;
+    mrpdr_column o[3];
+    for (int k = 0; k < 3; k++) {
+        d_val[k].resize(4 * caps[k]); d_cnt[k].resize(8); d_offs[k].resize(16);
+        o[k] = mrpdr_column();
+        o[k].values = d_val[k].ptr<void>(); o[k].counts = d_cnt[k].ptr<uint64_t>(); o[k].offs = d_offs[k].ptr<uint64_t>();
+        o[k].capacity = caps[k];
+    }
+    const uint64_t need = mrpdr_eqclass_scratch_bytes(cols[0].capacity);
+    d_scratch.resize(need);
+    if (!mrpdr_wave_int_eq_class(wc.ctx, &cols[0], &cols[1], &cols[2], in.size(), &o[0], &o[1], &o[2],
+                                 d_scratch.ptr<void>(), need, wc.stream)) throw PdrError("mrpdr_wave_int_eq_class");
+    out.assign(3, HostColumn());
+    for (int k = 0; k < 3; k++) download_single(wc, o[k], 4, false, out[k]);
+    return 0;
+}
 
 } // namespace MRN_GPU

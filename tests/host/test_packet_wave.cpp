@@ -256,6 +256,97 @@ static void test_builder_reader(WaveContext &wc)
     delete got;
 }
 
+// The array filters (src/FilterDefinitions.C:649-1239) on small waves whose results follow from
+// the reference's rules by hand.
+static void test_array_filters(WaveContext &wc)
+{
+    {   // tfilter_ArrayConcat: arrays of 2, 0 and 3 elements
+        std::vector<HostColumn> cols(1);
+        cols[0].set_arrays(std::vector<uint64_t>{2, 0, 3}, std::vector<int32_t>{1, 2, 3, 4, 5});
+        PacketWave sent(wc, 7, 100, "%ad", cols, 3);
+        PacketWave *got = received(wc, sent);
+        HostColumn out;
+        bool ok = tfilter_ArrayConcat(*got, out) == 0 && out.counts.size() == 1 && out.counts[0] == 5 &&
+                  out.values.size() == 20 && !memcmp(out.values.data(), cols[0].values.data(), 20);
+        std::vector<HostColumn> sc(1);
+        sc[0] = scalars<int32_t>(3, 1);
+        PacketWave scalar_wave(wc, 7, 100, "%d", sc, 3);
+        ok = ok && tfilter_ArrayConcat(scalar_wave, out) == -1;        // not an array format: nothing is emitted
+        end_SubTest("tfilter_ArrayConcat", ok);
+        delete got;
+    }
+    {   // tfilter_PerfData: ranks 0, 1 and an aggregate of 2 ranks
+        std::vector<HostColumn> cols(3);
+        cols[0].set_arrays(std::vector<uint64_t>{1, 1, 1}, std::vector<int32_t>{0, 1, -2});
+        cols[1].set_arrays(std::vector<uint64_t>{1, 1, 1}, std::vector<int32_t>{2, 2, 2});
+        cols[2].set_arrays(std::vector<uint64_t>{2, 2, 2}, std::vector<double>{1, 2, 3, 4, 10, 20});
+        PacketWave sent(wc, 7, 100, "%ad %ad %alf", cols, 3);
+        PacketWave *got = received(wc, sent);
+        std::vector<HostColumn> out;
+        bool ok = tfilter_PerfData(*got, MRPDR_SUM, out) == 0 && out[0].as<int32_t>()[0] == -4 &&
+                  out[1].as<int32_t>()[0] == 2 && out[2].counts[0] == 2 &&
+                  out[2].as<double>()[0] == 14.0 && out[2].as<double>()[1] == 26.0;
+        ok = ok && tfilter_PerfData(*got, MRPDR_AVG, out) == 0 && out[2].as<double>()[0] == 6.0 && out[2].as<double>()[1] == 11.5;
+        ok = ok && tfilter_PerfData(*got, MRPDR_MAX, out) == 0 && out[2].as<double>()[0] == 10.0 && out[2].as<double>()[1] == 20.0;
+        // MIN starts from bytes 0xFF, a NaN that the first '<' discards
+        ok = ok && tfilter_PerfData(*got, MRPDR_MIN, out) == 0 && out[2].as<double>()[0] == 1.0 && out[2].as<double>()[1] == 2.0;
+        ok = ok && tfilter_PerfData(*got, PERFDATA_ARRAY_CONCAT, out) == 0 && out[0].counts[0] == 3 && out[2].counts[0] == 6 &&
+             out[0].as<int32_t>()[2] == -2 && out[2].as<double>()[5] == 20.0;
+        end_SubTest("tfilter_PerfData(SUM, AVG, MAX, MIN, ARRAY_CONCAT)", ok);
+        delete got;
+    }
+    {   // tfilter_IntEqClass: classes 5 and 3, then 3 and 7
+        std::vector<HostColumn> cols(3);
+        cols[0].set_arrays(std::vector<uint64_t>{2, 2}, std::vector<uint32_t>{5, 3, 3, 7});
+        cols[1].set_arrays(std::vector<uint64_t>{2, 2}, std::vector<uint32_t>{2, 1, 1, 2});
+        cols[2].set_arrays(std::vector<uint64_t>{3, 3}, std::vector<uint32_t>{10, 11, 12, 20, 30, 31});
+        PacketWave sent(wc, 7, 100, "%aud %aud %aud", cols, 2);
+        std::vector<HostColumn> out;
+        const uint32_t v[3] = {3, 5, 7}, c[3] = {2, 2, 2}, m[6] = {12, 20, 10, 11, 30, 31};
+        bool ok = tfilter_IntEqClass(sent, out) == 0 && out[0].counts[0] == 3 && out[1].counts[0] == 3 && out[2].counts[0] == 6 &&
+                  !memcmp(out[0].values.data(), v, 12) && !memcmp(out[1].values.data(), c, 12) &&
+                  !memcmp(out[2].values.data(), m, 24);
+        end_SubTest("tfilter_IntEqClass", ok);
+    }
+}
+
+// A wave whose odd packets came from big-endian senders: every packet is decoded with the byte
+// order its own header announces (src/Packet.C:96,118).
+static void test_both_byte_orders(WaveContext &wc)
+{
+    const char *fmt = "%d %ad";
+    const uint64_t nb = 10;
+    std::vector<HostColumn> cols(2);
+    std::vector<int32_t> v(nb), arr(3 * nb);
+    for (uint64_t i = 0; i < nb; i++) v[i] = (int32_t)(i * 1000 - 7);
+    for (uint64_t i = 0; i < 3 * nb; i++) arr[i] = (int32_t)(0x01020300 + i);
+    cols[0].set_scalars(v);
+    cols[1].set_arrays(std::vector<uint64_t>(nb, 3), arr);
+    PacketWave sent(wc, 9, 101, fmt, cols, nb);
+    std::vector<uint8_t> hdrs, arena;
+    std::vector<uint64_t> offs, lens;
+    sent.get_Headers(hdrs);
+    sent.get_Buffers(arena, offs, lens);
+    const unsigned hl = sent.get_HeaderLen();
+    const size_t flen = strlen(fmt) + 1;
+    auto reverse = [](uint8_t *p, size_t w) { for (size_t k = 0; k < w / 2; k++) { uint8_t t = p[k]; p[k] = p[w - 1 - k]; p[w - 1 - k] = t; } };
+    for (uint64_t i = 1; i < nb; i += 2) {
+        uint8_t *h = hdrs.data() + i * hl, *b = arena.data() + offs[i];
+        for (int a = 0; a < 16; a += 4) reverse(h + a, 4);      // stream id, tag, source rank, format length
+        reverse(h + 16 + flen, 8);                              // destination count
+        h[hl - 1] = MRPDR_BIGENDIAN;
+        reverse(b, 4);                                          // %d
+        reverse(b + 4, 8);                                      // array count
+        for (int e = 0; e < 3; e++) reverse(b + 12 + 4 * e, 4);
+    }
+    PacketWave got(wc, fmt, nb, (const char *)hdrs.data(), hl, (const char *)arena.data(), offs.data(), lens.data(),
+                   arena.size());
+    std::vector<HostColumn> out;
+    bool ok = !got.has_Error() && got.get_StreamId() == 9 && got.get_Tag() == 101 && got.unpack(fmt, out) == 0 && !got.has_Error();
+    ok = ok && !memcmp(out[0].values.data(), v.data(), 4 * nb) && !memcmp(out[1].values.data(), arr.data(), 12 * nb);
+    end_SubTest("wave with packets of both byte orders", ok);
+}
+
 int main()
 {
     try {
@@ -278,6 +369,8 @@ int main()
         test_truncated(wc);
         test_string_arrays(wc);
         test_builder_reader(wc);
+        test_array_filters(wc);
+        test_both_byte_orders(wc);
     } catch (const std::exception &e) {
         printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
         failures++;
