@@ -509,3 +509,49 @@ def test_sizeof_large_waves(codec, n, align, phase):
         assert np.array_equal(W.Codec.to_numpy(offs).view(np.uint64), want_offs)
         assert total == int(want_offs[n])
     assert big.status() == 0
+
+
+def test_column_beyond_four_gibibytes(codec):
+    """'%Ad' packets whose arrays add up to more than 4 GiB (and more chunk descriptors than one
+    launch takes): 64-bit offsets everywhere, the payload kernel run in windows.  Checked through
+    size-independent properties, as the oracle's per-element path would take minutes here."""
+    counts = [600_000_001, 0, 550_000_000, 3]
+    n, total = len(counts), sum(counts)
+    assert 4 * total > (1 << 32)
+    fmt = W.Format("%Ad")
+    g = torch.Generator(device="cuda").manual_seed(41)
+    vals = torch.randint(-2**31, 2**31 - 1, (total,), dtype=torch.int32, device="cuda", generator=g)
+    lens_h = [8 + 4 * c for c in counts]
+    offs_h = [0]
+    for l in lens_h:
+        offs_h.append(offs_h[-1] + l + 5)                  # 5 bytes of slack between packets
+    be = torch.zeros(offs_h[-1], dtype=torch.uint8, device="cuda")
+    at = 0
+    for i, c in enumerate(counts):
+        p = offs_h[i]
+        be[p:p + 8] = torch.tensor(list(int(c).to_bytes(8, "big")), dtype=torch.uint8, device="cuda")
+        step = 1 << 27
+        for a in range(0, c, step):                         # in slices: the reversed copy stays small
+            b = min(c, a + step)
+            be[p + 8 + 4 * a:p + 8 + 4 * b] = vals[at + a:at + b].view(torch.uint8).view(-1, 4).flip(-1).reshape(-1)
+        at += c
+    offs = torch.tensor(offs_h, dtype=torch.int64, device="cuda")
+    lens = torch.tensor(lens_h, dtype=torch.int64, device="cuda")
+    wire = W.WireWave(be, n, offs, lens, 0)
+    cols, ok = codec.decode(fmt, wire, W.BIGENDIAN)
+    assert bool(ok.all()) and int(cols[0].offs[n]) == total
+    assert cols[0].counts.tolist() == counts
+    assert torch.equal(cols[0].values.view(torch.int32)[:total], vals)
+    del be, wire
+    le = codec.encode(fmt, cols, n)
+    assert le.lens.tolist() == lens_h
+    lo = le.offsets.tolist()
+    at = 0
+    for i, c in enumerate(counts):
+        p = lo[i]
+        # clones: a view at an odd offset cannot be reinterpreted in place
+        assert int(le.arena[p:p + 8].clone().view(torch.int64).item()) == c
+        if c:
+            assert torch.equal(le.arena[p + 8:p + 8 + 4 * c].clone().view(torch.int32), vals[at:at + c])
+        at += c
+    assert codec.status() == 0
