@@ -85,6 +85,16 @@ template <int OP, typename T> struct Folder {
         }
         any = true;
     }
+    // add() for a fold that has taken at least one element: the same arithmetic, no flag to test
+    __device__ inline void add_more(T x, int32_t c)
+    {
+        if (OP == MRPDR_SUM) res = (T)(res + x);
+        else if (OP == MRPDR_MAX) res = (res > x) ? res : x;
+        else if (OP == MRPDR_MIN) res = (res < x) ? res : x;
+        else if (OP == MRPDR_OR) res = or_bits<false>(res, x);
+        else if (OP == MRPDR_AND) res = or_bits<true>(res, x);
+        else { res = (T)(res + mul_cnt<T>(x, c)); cnt += c; }
+    }
     // false: the node is absent (no child, or an AVG whose counts sum to zero)
     __device__ inline bool finish()
     {
@@ -227,8 +237,22 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Par
 // One lane folds m staged nodes in order.  Eight LDS reads are issued before the first of them is
 // used: the fold is a dependent chain, the reads need not be.
 template <int OP, typename T>
-__device__ inline void fold_nodes(Folder<OP, T> &g, const Partial *stage, uint32_t m)
+__device__ inline void fold_nodes(Folder<OP, T> &g, const Partial *stage, uint32_t m, bool dense)
 {
+    if (dense && m) {
+        // every staged node is present (all but degenerate waves): a straight dependent chain of
+        // the operator itself, nothing else between two links
+        g.add(from_bits<T>(stage[0].bits), stage[0].cnt);
+        for (uint32_t k = 1; k < m; k += 8) {
+            Partial p[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) p[j] = stage[(k + j < m) ? k + j : k];
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (k + j < m) g.add_more(from_bits<T>(p[j].bits), p[j].cnt);
+        }
+        return;
+    }
     for (uint32_t k = 0; k < m; k += 8) {
         Partial p[8];
 #pragma unroll
@@ -253,9 +277,13 @@ __device__ inline void tree_top(const Partial *partials, uint64_t np, uint8_t *r
     for (uint64_t base = 0; base < np; base += FLAT_TILE) {
         const uint32_t m = (uint32_t)((np - base) < FLAT_TILE ? (np - base) : FLAT_TILE);
         __syncthreads();
-        for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) stage[k] = partials[base + k];
-        __syncthreads();
-        if (threadIdx.x == 0) fold_nodes<OP, T>(g, stage, m);
+        int all = 1;
+        for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) {
+            stage[k] = partials[base + k];
+            all &= stage[k].present;
+        }
+        const bool dense = __syncthreads_and(all) != 0;
+        if (threadIdx.x == 0) fold_nodes<OP, T>(g, stage, m, dense);
     }
     if (threadIdx.x == 0) {
         const bool present = g.finish();
@@ -308,14 +336,16 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_stats_top(const Partial *p
     for (uint64_t base = 0; base < np; base += STATS_TILE) {
         const uint32_t m = (uint32_t)((np - base) < STATS_TILE ? (np - base) : STATS_TILE);
         __syncthreads();
+        int all = 1;
         for (uint32_t k = threadIdx.x; k < 3 * m; k += MRPDR_TPB) {
             const uint32_t o = k / m, j = k - o * m;
             stage[o][j] = partials[o * stride + base + j];
+            all &= stage[o][j].present;
         }
-        __syncthreads();
-        if (mine == 0) fold_nodes<MRPDR_MIN, T>(gmin, stage[0], m);
-        else if (mine == 1) fold_nodes<MRPDR_MAX, T>(gmax, stage[1], m);
-        else if (mine == 2) fold_nodes<MRPDR_AVG, T>(gavg, stage[2], m);
+        const bool dense = __syncthreads_and(all) != 0;
+        if (mine == 0) fold_nodes<MRPDR_MIN, T>(gmin, stage[0], m, dense);
+        else if (mine == 1) fold_nodes<MRPDR_MAX, T>(gmax, stage[1], m, dense);
+        else if (mine == 2) fold_nodes<MRPDR_AVG, T>(gavg, stage[2], m, dense);
     }
     if (mine == 0) { const bool p = gmin.finish(); write_result<MRPDR_MIN, T>(results, oks, p, gmin.res, gmin.cnt); }
     if (mine == 1) { const bool p = gmax.finish(); write_result<MRPDR_MAX, T>(results + 16, oks + 1, p, gmax.res, gmax.cnt); }
