@@ -20,6 +20,9 @@
  *   - nothing is thrown across this boundary; no torch/C++ types appear in it
  *   - a mrpdr_ctx owns a small device workspace; calls using the same ctx must
  *     not overlap in time (use one ctx per calling thread / stream)
+ *   - a mrpdr_ctx belongs to the device it was created on; that device must be the
+ *     calling thread's current HIP device (hipSetDevice) whenever the ctx is used,
+ *     otherwise the call returns FALSE
  *   - the device is little-endian: mrpdr_local_byteorder() == 0
  */
 #ifndef MRPDR_H

@@ -350,9 +350,21 @@ static inline uint32_t blocks_for(uint64_t n, uint32_t per_block)
     return (uint32_t)((n + per_block - 1) / per_block);
 }
 
-static int32_t check_common(const char *who, const mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n)
+// The workspace of a ctx lives on one device, and kernels launch on the calling thread's current
+// device: the two must be the same (a kernel given another device's pointers faults).
+static int32_t ctx_ready(const char *who, const mrpdr_ctx *c)
 {
     if (!c) return fail("%s: NULL ctx", who);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return fail("%s: no current HIP device", who);
+    if (cur != c->device)
+        return fail("%s: the ctx belongs to device %d but device %d is current (hipSetDevice first)", who, c->device, cur);
+    return 1;
+}
+
+static int32_t check_common(const char *who, const mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n)
+{
+    if (!ctx_ready(who, c)) return 0;
     if (!f) return fail("%s: NULL format", who);
     if (n > c->max_packets) return fail("%s: n=%llu exceeds the ctx limit %llu", who,
                                         (unsigned long long)n, (unsigned long long)c->max_packets);
@@ -879,7 +891,7 @@ extern "C" int32_t mrpdr_wave_encode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
                                              uint8_t *hdrs, const uint64_t *hdr_offsets, uint64_t hdr_stride,
                                              void *stream)
 {
-    if (!c) return fail("mrpdr_wave_encode_headers: NULL ctx");
+    if (!ctx_ready("mrpdr_wave_encode_headers", c)) return 0;
     HdrImage img;
     if (!make_image("mrpdr_wave_encode_headers", f, &img)) return 0;
     if (ndest && !dest_ranks) return fail("mrpdr_wave_encode_headers: NULL destination list");
@@ -901,7 +913,7 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
                                              uint32_t *dest_ranks, uint64_t dest_stride, int32_t *ok,
                                              void *stream)
 {
-    if (!c) return fail("mrpdr_wave_decode_headers: NULL ctx");
+    if (!ctx_ready("mrpdr_wave_decode_headers", c)) return 0;
     HdrImage img;
     if (!make_image("mrpdr_wave_decode_headers", f, &img)) return 0;
     if (n == 0) return 1;
@@ -921,7 +933,7 @@ extern "C" uint64_t mrpdr_message_preamble_bytes(uint64_t n) { return MSG_COUNT_
 extern "C" int32_t mrpdr_message_write_preamble(mrpdr_ctx *c, uint64_t n, uint64_t hdr_len, const uint64_t *lens,
                                                 uint8_t *msg, void *stream)
 {
-    if (!c) return fail("mrpdr_message_write_preamble: NULL ctx");
+    if (!ctx_ready("mrpdr_message_write_preamble", c)) return 0;
     if (!msg || (n && !lens)) return fail("mrpdr_message_write_preamble: NULL argument");
     if (n > 0xFFFFFFFFull) return fail("mrpdr_message_write_preamble: the packet count is a uint32 on the wire");
     k_msg_preamble<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(msg, n, hdr_len, lens);
@@ -934,7 +946,7 @@ extern "C" int32_t mrpdr_message_parse_sizes(mrpdr_ctx *c, const uint8_t *sizes,
                                              uint64_t *buf_offsets, uint64_t *buf_lens,
                                              uint64_t *payload_bytes_host, void *stream)
 {
-    if (!c) return fail("mrpdr_message_parse_sizes: NULL ctx");
+    if (!ctx_ready("mrpdr_message_parse_sizes", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_message_parse_sizes: n exceeds the ctx limit");
     if (!hdr_offsets || !buf_offsets || (n && (!sizes || !hdr_lens || !buf_lens)))
         return fail("mrpdr_message_parse_sizes: NULL argument");
@@ -996,7 +1008,7 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
                                      uint64_t n, int32_t swap,
                                      void *result, int32_t *result_ok, void *stream)
 {
-    if (!c) return fail("mrpdr_wave_filter: NULL ctx");
+    if (!ctx_ready("mrpdr_wave_filter", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_filter: n exceeds the ctx limit");
     if (!result) return fail("mrpdr_wave_filter: NULL result");
     if (n && !values) return fail("mrpdr_wave_filter: NULL values");
@@ -1040,7 +1052,7 @@ extern "C" int32_t mrpdr_wave_filter_stats(mrpdr_ctx *c, int32_t type, const voi
                                            const void *counts, uint64_t count_stride, uint64_t n, int32_t swap,
                                            void *results, int32_t *results_ok, void *stream)
 {
-    if (!c) return fail("mrpdr_wave_filter_stats: NULL ctx");
+    if (!ctx_ready("mrpdr_wave_filter_stats", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_filter_stats: n exceeds the ctx limit");
     if (!results || !results_ok) return fail("mrpdr_wave_filter_stats: NULL result");
     if (n && (!values || !counts)) return fail("mrpdr_wave_filter_stats: NULL values or counts");
@@ -1079,6 +1091,7 @@ extern "C" int32_t mrpdr_wave_array_concat(mrpdr_ctx *c, const mrpdr_column *in,
                                            mrpdr_column *out, void *stream)
 {
     if (!c || !in || !out) return fail("mrpdr_wave_array_concat: NULL argument");
+    if (!ctx_ready("mrpdr_wave_array_concat", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_array_concat: n exceeds the ctx limit");
     if (!in->offs || !out->counts || !out->offs) return fail("mrpdr_wave_array_concat: counts / offs missing");
     k_concat_column<<<1, 1, 0, (hipStream_t)stream>>>(in->offs, n, out->counts, out->offs, c->status);
@@ -1121,6 +1134,7 @@ extern "C" int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *c, const mrpdr_colu
                                                   mrpdr_column *out, void *stream)
 {
     if (!c || !in || !out || !mask_counts) return fail("mrpdr_wave_array_concat_masked: NULL argument");
+    if (!ctx_ready("mrpdr_wave_array_concat_masked", c)) return 0;
     if (n == 0 || n > c->max_packets) return fail("mrpdr_wave_array_concat_masked: bad n");
     if (!in->counts || !in->offs || !out->counts || !out->offs || (out->capacity && !out->values))
         return fail("mrpdr_wave_array_concat_masked: columns need counts, offs and values");
@@ -1195,6 +1209,7 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
                                        void *scratch, uint64_t scratch_bytes, void *stream)
 {
     if (!c || !ranks || !data || !out_len || !out_rank) return fail("mrpdr_wave_perfdata: NULL argument");
+    if (!ctx_ready("mrpdr_wave_perfdata", c)) return 0;
     if (n == 0) return fail("mrpdr_wave_perfdata: empty wave (the reference emits nothing)");
     if (n > c->max_packets) return fail("mrpdr_wave_perfdata: n exceeds the ctx limit");
     if (!ranks->counts || !ranks->offs || !data->counts || !data->offs)
@@ -1242,6 +1257,7 @@ extern "C" int32_t mrpdr_wave_int_eq_class(mrpdr_ctx *c, const mrpdr_column *val
 {
     if (!c || !vals || !memcnts || !mems || !out_vals || !out_memcnts || !out_mems)
         return fail("mrpdr_wave_int_eq_class: NULL argument");
+    if (!ctx_ready("mrpdr_wave_int_eq_class", c)) return 0;
     if (n == 0) return fail("mrpdr_wave_int_eq_class: empty wave (the reference emits nothing useful)");
     if (n > c->max_packets) return fail("mrpdr_wave_int_eq_class: n exceeds the ctx limit");
     if (!vals->offs || !mems->offs) return fail("mrpdr_wave_int_eq_class: columns need offs");
