@@ -424,7 +424,10 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
     // in packet order per element, as the reference's, and then reads LDS only.
     __shared__ uint64_t s_len[MRPDR_TPB], s_off[MRPDR_TPB];
     __shared__ int32_t s_nrank[MRPDR_TPB];
+    __shared__ uint4 s_rec[MRPDR_TPB];           // staged tiles: {position in s_data, length, rank count, -}
     __shared__ T s_data[PERF_STAGE_ELEMS];
+    __shared__ uint32_t s_total;
+    __shared__ unsigned long long s_longest;
     const uint64_t g = blockIdx.y;
     const uint32_t t = threadIdx.x;
     const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + t;
@@ -434,55 +437,67 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
     __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
     uint32_t total = 0;
     uint64_t longest = 0, last = 0;
+    if (t == 0) { s_total = 0; s_longest = 0; }
     for (uint64_t p0 = i0; p0 < i1; p0 += MRPDR_TPB) {
         const uint32_t np = (uint32_t)((i1 - p0) < MRPDR_TPB ? (i1 - p0) : MRPDR_TPB);
         __syncthreads();
+        // The rank total and the longest array do not depend on the order of the packets: the
+        // lanes that load the tile's lengths add them up (wavefront first, then LDS), which
+        // leaves the serial loop below with the fold alone.
+        uint32_t my_ranks = 0;
+        uint64_t my_len = 0;
         if (t < np) {
             const uint64_t len = in.data_counts[p0 + t];
             s_len[t] = len;
             s_off[t] = in.data_offs[p0 + t];
             int32_t rank = 0;
             if (len && in.rank_counts[p0 + t]) rank = in.rank_vals[in.rank_offs[p0 + t]];
-            s_nrank[t] = rank < 0 ? -rank : 1;
+            const int32_t nrank = rank < 0 ? -rank : 1;
+            s_nrank[t] = nrank;
+            my_ranks = len ? (uint32_t)nrank : 0u;
+            my_len = len;
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            my_ranks += __shfl_xor(my_ranks, m, 64);
+            const uint64_t o = __shfl_xor((unsigned long long)my_len, m, 64);
+            my_len = o > my_len ? o : my_len;
+        }
+        if ((t & 63u) == 0) {
+            atomicAdd(&s_total, my_ranks);
+            atomicMax(&s_longest, (unsigned long long)my_len);
         }
         __syncthreads();
         const uint64_t base = s_off[0], run = s_off[np - 1] + s_len[np - 1] - base;
         // staged only by the workgroup of the first 256 elements: longer arrays read the column
         // with full wavefronts anyway
         const bool staged = gridDim.x == 1 && s_off[np - 1] >= base && run <= PERF_STAGE_ELEMS;
+        last = s_len[np - 1];
         if (staged) {
+            if (t < np) s_rec[t] = make_uint4((uint32_t)(s_off[t] - base), (uint32_t)s_len[t], (uint32_t)s_nrank[t], 0u);
             for (uint64_t k = t; k < run; k += MRPDR_TPB) s_data[k] = data[base + k];
             __syncthreads();
-        }
-        if (staged) {
             // branch-free so that the LDS reads of several packets are in flight together; the
             // fold itself stays in packet order
 #pragma unroll 8
             for (uint32_t j = 0; j < np; j++) {
-                const uint64_t len = s_len[j];
-                const int32_t nrank = s_nrank[j];
-                const bool active = u < len;
-                const uint64_t k = active ? s_off[j] - base + u : 0;
-                const T x = s_data[k];
-                total += len ? (uint32_t)nrank : 0u;
-                longest = len > longest ? len : longest;
-                const T f = perf_fold<OP, T>(acc, x, nrank);
+                const uint4 r = s_rec[j];
+                const bool active = t < r.y;
+                const T x = s_data[active ? r.x + t : 0u];
+                const T f = perf_fold<OP, T>(acc, x, (int32_t)r.z);
                 acc = active ? f : acc;
             }
-            last = s_len[np - 1];
         } else {
 #pragma unroll 4
             for (uint32_t j = 0; j < np; j++) {
                 const uint64_t len = s_len[j];
-                last = len;
-                if (!len) continue;
-                const int32_t nrank = s_nrank[j];
-                total += (uint32_t)nrank;
-                if (len > longest) longest = len;
-                if (u < len) acc = perf_fold<OP, T>(acc, data[s_off[j] + u], nrank);
+                if (u < len) acc = perf_fold<OP, T>(acc, data[s_off[j] + u], s_nrank[j]);
             }
         }
     }
+    __syncthreads();
+    total = s_total;
+    longest = s_longest;
     if (OP == MRPDR_AVG && last && u < last) {
         acc = acc / (T)total;          // unsigned total converted to the element type, as the reference's /=
     }
