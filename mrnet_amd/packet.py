@@ -256,6 +256,43 @@ def tfilter_IntEqClass(ipackets):
     return _from_columns(ipackets, fmt, ipackets.codec.int_eq_class(cols[0], cols[1], cols[2], ipackets.n))
 
 
+def aggr_FieldSums(ipackets, shape=W.SHAPE_TREE):
+    """The user filters of tests/test_DynamicFilters.C:12-58 (aggr_Count on '%d',
+    aggr_CountOddsAndEvens on '%d %d') and Examples/IntegerAddition/IntegerAdditionFilter.C:15-35:
+    unpack every packet, add each field up in its own C type, emit one packet of the same format.
+    Any format of scalars only is taken; one fold per field, straight on the packed wire."""
+    codec, fmt, n = ipackets.codec, ipackets.fmt, ipackets.n
+    if n == 0 or ipackets.has_Error() or not fmt.is_fixed or len(fmt) == 0:
+        return None
+    out_bytes = torch.zeros(fmt.fixed_bytes, dtype=torch.uint8, device=codec.device)
+    wire = ipackets.wire
+    packed = wire.offsets is None and not isinstance(ipackets.byteorder, torch.Tensor)
+    cols = None if packed else ipackets.unpack(fmt.text)
+    if ipackets.has_Error():
+        return None
+    at = 0
+    for f, w in enumerate(fmt.widths):
+        if packed:
+            res, _ = codec.filter_raw(W.TFILTER_SUM, fmt.types[f], wire.arena.data_ptr() + at, wire.stride, None, 0, n,
+                                      int(ipackets.byteorder != W.LITTLEENDIAN), shape)
+        else:
+            res, _ = codec.filter_columns(W.TFILTER_SUM, fmt.types[f], cols[f].values, None, shape)
+        out_bytes[at:at + w] = res[:w]
+        at += w
+    out = PacketWave.__new__(PacketWave)
+    out.codec, out.fmt, out.n = codec, fmt, 1
+    out.stream_id, out.tag = ipackets.get_StreamId(), ipackets.get_Tag()
+    out.src_rank, out.src_ranks, out.inlet_rank = W.UNKNOWN_RANK, None, W.UNKNOWN_RANK
+    out._hdrs, out._error, out.byteorder = None, False, W.LITTLEENDIAN
+    out.wire = W.WireWave(out_bytes, 1, None, None, fmt.fixed_bytes)      # the sums ARE the encoded data
+    out.columns, out.ok, out._decoded = None, None, False
+    return out
+
+
+aggr_Count = aggr_FieldSums               # tests/test_DynamicFilters.C:12-33
+aggr_CountOddsAndEvens = aggr_FieldSums   # tests/test_DynamicFilters.C:35-58
+
+
 def BitsetOr(ipackets, shape=W.SHAPE_TREE):
     """Examples/FaultRecovery/FaultRecoveryFilter.C:107-128: one '%uld' packet, the OR of all inputs."""
     if ipackets.fmt.text != "%uld":

@@ -186,3 +186,31 @@ def test_wave_from_children_of_both_byte_orders(codec):
     g1 = PacketWave.from_buffers(codec, "%d", n, codec.to_device(h1.reshape(-1)), s.get_HeaderLen(), w1)
     out = tfilter_Sum(g1)
     assert out is not None and int(W.Codec.to_numpy(out.unpack("%d")[0].values).view(np.int32)[0]) == int(vals.sum())
+
+
+@pytest.mark.parametrize("num_backends", [1, 4, 16, 2000])
+def test_dynamic_filters(codec, num_backends):
+    """tests/test_DynamicFilters_FE.C:94-124, 152-200 with tests/test_DynamicFilters_BE.C:34-47:
+    every back-end sends 1 (aggr_Count must return the number of end points) and (odd, even)
+    flags of its rank (aggr_CountOddsAndEvens must return how many of each there are)."""
+    from mrnet_amd.packet import aggr_Count, aggr_CountOddsAndEvens
+    n = num_backends
+    ones = PacketWave(codec, 11, 103, "%d", [np.ones(n, dtype=np.int32)])
+    got = PacketWave.from_buffers(codec, "%d", n, ones.get_Header(), ones.get_HeaderLen(), ones.get_Buffer())
+    out = aggr_Count(got)
+    assert out.get_StreamId() == 11 and out.get_Tag() == 103
+    assert int(W.Codec.to_numpy(out.unpack("%d")[0].values).view(np.int32)[0]) == n
+    ranks = np.arange(n)
+    odd, even = (ranks % 2 == 1).astype(np.int32), (ranks % 2 == 0).astype(np.int32)
+    flags = PacketWave(codec, 11, 104, "%d %d", [odd, even])
+    got = PacketWave.from_buffers(codec, "%d %d", n, flags.get_Header(), flags.get_HeaderLen(), flags.get_Buffer())
+    cols = aggr_CountOddsAndEvens(got).unpack("%d %d")
+    assert int(W.Codec.to_numpy(cols[0].values).view(np.int32)[0]) == n // 2
+    assert int(W.Codec.to_numpy(cols[1].values).view(np.int32)[0]) == (n + 1) // 2
+    # mixed scalar types wrap in their own C type, as "sum += v" in the filter's C code does
+    mixed = PacketWave(codec, 11, 105, "%uc %hd %lf", [np.full(n, 200, np.uint8), np.full(n, -30000, np.int16),
+                                                      np.full(n, 0.5, np.float64)])
+    c3 = aggr_Count(mixed).unpack("%uc %hd %lf")
+    assert int(W.Codec.to_numpy(c3[0].values).view(np.uint8)[0]) == (200 * n) % 256
+    assert int(W.Codec.to_numpy(c3[1].values).view(np.int16)[0]) == np.int16((-30000 * n + 32768) % 65536 - 32768)
+    assert float(W.Codec.to_numpy(c3[2].values).view(np.float64)[0]) == 0.5 * n
