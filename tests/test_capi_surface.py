@@ -36,6 +36,15 @@ def test_no_torch_types_in_the_abi():
     assert "torch" not in text and "at::" not in text and "std::" not in text
 
 
+def test_header_is_plain_c():
+    """The boundary is a C ABI: the header must compile as C99 (the lightweight back-end library
+    of the reference is C, src/lightweight/)."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c",
+                        os.path.join(ROOT, "include", "mrpdr.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 FORMATS = ["%d", "%c %uc %hd %uhd %d %ud %ld %uld %f %lf %s", "%d %uld %lf %s %auc", "%af",
            "%lf %d", "%ad %ad %alf", "%Ac %Auc %Ahd %Auhd %Ad %Aud %Ald %Auld %Af %Alf",
            "%d\t%d\n%d%d", ""]
