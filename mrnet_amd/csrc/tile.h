@@ -140,10 +140,72 @@ __device__ __forceinline__ void tile_copy_run(uint8_t *w, uint8_t *d, uint64_t l
     }
 }
 
+// Encode into the image: the same packet-by-packet copy with the global loads of a lane's four
+// packets (two 128-bit pieces each, then one tail element each) all issued before the first LDS
+// store.  A lane waits for memory twice per field instead of once per piece: the loads are
+// what the staged encode spends its time on, the stores go to LDS.
+template <int W>
+__device__ __forceinline__ void tile_fill_field(TileLds &m, uint8_t *img, int v, uint32_t pre, const uint8_t *dense,
+                                                uint32_t np, uint64_t lo, uint32_t mis)
+{
+    typedef typename UIntOf<W>::type U;
+    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
+    const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
+    uint8_t *w[PK];
+    const uint8_t *d[PK];
+    uint32_t len[PK];
+    bool more = false;
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
+        len[k] = 0; w[k] = img; d[k] = dense;
+        if (i < np) {
+            const uint64_t s_lo = m.seg[v][i] * W;
+            len[k] = (uint32_t)(m.seg[v][i + 1] * W - s_lo);      // a staged tile holds less than 24 KiB
+            w[k] = tile_at<true>(img, nullptr, lo, mis, m.start[i] + m.vpos[v][i] + pre);
+            d[k] = dense + s_lo;
+            more |= len[k] > 512u;
+        }
+    }
+    u32x4 r[PK][2];
+#pragma unroll
+    for (int k = 0; k < PK; k++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+            if (o + 16u <= len[k]) r[k][q] = ld16_any<false>(d[k] + o);
+        }
+    U tail[PK];
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        const uint32_t o = (len[k] & ~15u) + lane * W;
+        if (o < len[k]) tail[k] = ld_u<U>(d[k] + o);
+    }
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+            if (o + 16u <= len[k]) st16_u(w[k] + o, r[k][q]);
+        }
+        const uint32_t o = (len[k] & ~15u) + lane * W;
+        if (o < len[k]) st_u<U>(w[k] + o, tail[k]);
+    }
+    if (!more) return;
+    // payloads beyond 512 bytes: the remaining whole pieces, one at a time
+#pragma unroll
+    for (int k = 0; k < PK; k++)
+        for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u) st16_u(w[k] + o, ld16_any<false>(d[k] + o));
+}
+
 template <bool STAGED, bool ENCODE, bool SWAP, int W>
 __device__ __forceinline__ void tile_copy_field(TileLds &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
                                                 uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
 {
+    if (STAGED && ENCODE) {
+        tile_fill_field<W>(m, img, v, pre, dense, np, lo, mis);
+        return;
+    }
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
     for (uint32_t i = g; i < np; i += MRPDR_TPB / 16) {
         const uint64_t s_lo = m.seg[v][i] * W, len = m.seg[v][i + 1] * W - s_lo;
@@ -198,22 +260,34 @@ __device__ __forceinline__ void tile_encode_body(TileLds &m, uint8_t *img, const
     }
     // scalars and length prefixes: one (field, packet) pair per thread, field-major so that the
     // column reads of neighbouring lanes are neighbours
-    for (uint32_t idx = t; idx < (uint32_t)fmt.nf * np; idx += MRPDR_TPB) {
-        const int f = (int)(idx / np);
-        const uint32_t i = idx - (uint32_t)f * np;
-        const FieldDev fd = fmt.f[f];
-        const uint64_t pos = fd.fixed_before + tile_var_before(m, tv, fmt, f, i);
-        uint8_t *dst = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + pos);
-        if (fd.kind == MRPDR_SCALAR) {
-            const uint32_t w = fd.width;
-            st_w(dst, (int)w, ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + (p0 + i) * w, (int)w, false));
-        } else {
-            int v = 0;
-            while (tv.field[v] != f) v++;
-            const uint64_t cnt = m.seg[v][i + 1] - m.seg[v][i];
-            if (fd.kind == MRPDR_ARRAY) st_u<uint64_t>(dst, cnt);      // pdr_uint64(count), src/pdr.c:425
-            else                        st_u<uint32_t>(dst, (uint32_t)cnt);   // strlen+1, src/pdr.c:295-297
+    // (two pairs per trip: both column loads are issued before the first store)
+    for (uint32_t idx0 = t; idx0 < (uint32_t)fmt.nf * np; idx0 += 2 * MRPDR_TPB) {
+        uint64_t val[2];
+        uint8_t *dst[2];
+        uint32_t wid[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t idx = idx0 + (uint32_t)q * MRPDR_TPB;
+            wid[q] = 0; val[q] = 0; dst[q] = nullptr;
+            if (idx >= (uint32_t)fmt.nf * np) continue;
+            const int f = (int)(idx / np);
+            const uint32_t i = idx - (uint32_t)f * np;
+            const FieldDev fd = fmt.f[f];
+            const uint64_t pos = fd.fixed_before + tile_var_before(m, tv, fmt, f, i);
+            dst[q] = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + pos);
+            if (fd.kind == MRPDR_SCALAR) {
+                wid[q] = fd.width;
+                val[q] = ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + (p0 + i) * fd.width, (int)fd.width, false);
+            } else {
+                int v = 0;
+                while (tv.field[v] != f) v++;
+                val[q] = m.seg[v][i + 1] - m.seg[v][i];
+                wid[q] = fd.kind == MRPDR_ARRAY ? 8u : 4u;   // pdr_uint64(count), src/pdr.c:425; strlen+1, :295-297
+            }
         }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (wid[q]) st_w(dst[q], (int)wid[q], val[q]);
     }
     __syncthreads();
     tile_copy_fields<STAGED, true, false>(m, img, fmt, tv, wire, cols, np);
