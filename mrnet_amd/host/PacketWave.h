@@ -25,6 +25,7 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/mrpdr.h"
@@ -588,6 +589,34 @@ class PacketWave {
     std::vector<int32_t> ok_;
     mrpdr_wire wire_{};
 };
+
+// ---- waves of several formats -----------------------------------------------------------------
+// The built-in filters only assert that a wave has one format (src/FilterDefinitions.C:104-105);
+// a batched codec has to split first.  Host-side, on the header bytes as Message::recv left
+// them: the format string sits behind four 32-bit words (src/Packet.C:557-575), its length in
+// the header's own byte order (the last byte, src/Packet.C:96).  Returns the packet indices of
+// every format in arrival order; headers that cannot hold a format string go under "".
+inline std::vector<std::pair<std::string, std::vector<uint64_t> > >
+group_by_format(const uint8_t *hdrs, uint64_t hdrs_bytes, const uint64_t *hdr_offsets, const uint64_t *hdr_lens, uint64_t n)
+{
+    std::vector<std::pair<std::string, std::vector<uint64_t> > > groups;
+    for (uint64_t i = 0; i < n; i++) {
+        std::string key;
+        const uint64_t o = hdr_offsets[i], l = hdr_lens[i];
+        if (l >= 16 + 1 + 8 + 1 && o <= hdrs_bytes && l <= hdrs_bytes - o) {
+            const uint8_t *h = hdrs + o;
+            const bool be = h[l - 1] != MRPDR_LITTLEENDIAN;
+            const uint32_t flen = be ? ((uint32_t)h[12] << 24 | (uint32_t)h[13] << 16 | (uint32_t)h[14] << 8 | h[15])
+                                     : ((uint32_t)h[15] << 24 | (uint32_t)h[14] << 16 | (uint32_t)h[13] << 8 | h[12]);
+            if (flen >= 1 && flen <= l - 16 - 8 - 1 && h[16 + flen - 1] == 0) key.assign((const char *)h + 16, flen - 1);
+        }
+        size_t g = 0;
+        while (g < groups.size() && groups[g].first != key) g++;
+        if (g == groups.size()) groups.push_back(std::make_pair(key, std::vector<uint64_t>()));
+        groups[g].second.push_back(i);
+    }
+    return groups;
+}
 
 // ---- built-in transformation filters over a wave ------------------------------------------
 // Returns 0 and the data bytes of the output packet (T value[, int32 count]) in result16, or -1

@@ -148,6 +148,27 @@ _SCALAR_FORMATS = {"%c": W.DataType.CHAR_T, "%uc": W.DataType.UCHAR_T, "%hd": W.
                    "%lf": W.DataType.DOUBLE_T}
 
 
+def group_by_format(hdrs, hdr_offsets, hdr_lens):
+    """Host-side grouping of received packets by format string, in arrival order within a group.
+    hdrs: the header bytes as they arrived (numpy uint8, host memory -- Message::recv leaves them
+    there); hdr_offsets / hdr_lens: where each header lies.  The format string sits behind four
+    32-bit words (src/Packet.C:557-575), its length in the header's own byte order (last byte,
+    src/Packet.C:96).  Returns {format string: numpy array of packet indices}; packets whose
+    header cannot hold a format string go under None.  The built-in filters only assert that a
+    wave has one format (src/FilterDefinitions.C:104-105); a batched codec has to split first."""
+    hdrs = np.ascontiguousarray(hdrs, dtype=np.uint8)
+    groups = {}
+    for i, (o, l) in enumerate(zip(np.asarray(hdr_offsets, dtype=np.int64), np.asarray(hdr_lens, dtype=np.int64))):
+        key = None
+        if l >= 16 + 1 + 8 + 1 and o >= 0 and o + l <= hdrs.size:
+            h = hdrs[o:o + l]
+            flen = int.from_bytes(h[12:16].tobytes(), "big" if h[l - 1] != W.LITTLEENDIAN else "little")
+            if 1 <= flen <= l - 16 - 8 - 1 and h[16 + flen - 1] == 0:
+                key = h[16:16 + flen - 1].tobytes().decode("latin-1")
+        groups.setdefault(key, []).append(i)
+    return {k: np.asarray(v, dtype=np.int64) for k, v in groups.items()}
+
+
 def _run_filter(op, ipackets, shape):
     codec, fmt = ipackets.codec, ipackets.fmt
     if ipackets.n == 0 or ipackets.has_Error():

@@ -347,6 +347,32 @@ static void test_both_byte_orders(WaveContext &wc)
     end_SubTest("wave with packets of both byte orders", ok);
 }
 
+// Packets of two formats in one arrival: split by format string on the host, one wave each.
+static void test_group_by_format(WaveContext &wc)
+{
+    std::vector<HostColumn> a(1), b(2);
+    a[0] = scalars<int32_t>(3, 5);
+    b[0] = scalars<int32_t>(2, 6);
+    b[1] = strings(2, "x");
+    PacketWave wa(wc, 7, 100, "%d", a, 3), wb(wc, 7, 100, "%d %s", b, 2);
+    std::vector<uint8_t> ha, hb, all;
+    wa.get_Headers(ha);
+    wb.get_Headers(hb);
+    const unsigned la = wa.get_HeaderLen(), lb = wb.get_HeaderLen();
+    // arrival order: a0 b0 a1 a2 b1
+    std::vector<uint64_t> offs, lens;
+    const int order[5] = {0, 100, 1, 2, 101};
+    for (int k : order) {
+        offs.push_back(all.size());
+        if (k < 100) { all.insert(all.end(), ha.begin() + k * la, ha.begin() + (k + 1) * la); lens.push_back(la); }
+        else { all.insert(all.end(), hb.begin() + (k - 100) * lb, hb.begin() + (k - 99) * lb); lens.push_back(lb); }
+    }
+    auto g = group_by_format(all.data(), all.size(), offs.data(), lens.data(), 5);
+    bool ok = g.size() == 2 && g[0].first == "%d" && g[1].first == "%d %s" &&
+              g[0].second == std::vector<uint64_t>({0, 2, 3}) && g[1].second == std::vector<uint64_t>({1, 4});
+    end_SubTest("group_by_format", ok);
+}
+
 int main()
 {
     try {
@@ -371,6 +397,7 @@ int main()
         test_builder_reader(wc);
         test_array_filters(wc);
         test_both_byte_orders(wc);
+        test_group_by_format(wc);
     } catch (const std::exception &e) {
         printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
         failures++;

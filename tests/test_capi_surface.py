@@ -98,3 +98,30 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, fn), errors="ignore").read()
                 assert "pdr_oracle" not in text and "oracle." not in text and "import oracle" not in text, \
                     "%s refers to the oracle" % fn
+
+
+def test_group_by_format_host_logic():
+    """Packets of several formats and both byte orders split by format string (host logic only)."""
+    import numpy as np
+    from mrnet_amd.packet import group_by_format
+    fmts = ["%d", "%d %uld %lf %s %auc", "%d", "%af", "%d %uld %lf %s %auc", "%d"]
+    hdrs, offs, lens = [], [], []
+    at = 3                                                   # headers need not start at offset 0
+    blob = bytearray(b"\xee" * at)
+    for i, f in enumerate(fmts):
+        h = O.header_encode(7 + i, 100, i, f).copy()
+        if i % 2:                                            # as a big-endian sender writes it
+            for a in (0, 4, 8, 12):
+                h[a:a + 4] = h[a:a + 4][::-1].copy()
+            e = 16 + len(f) + 1
+            h[e:e + 8] = h[e:e + 8][::-1].copy()
+            h[-1] = 1
+            assert O.header_decode(h)["fmt"] == f
+        offs.append(len(blob)); lens.append(h.size)
+        blob += h.tobytes() + b"\xee\xee"
+    offs.append(len(blob)); lens.append(5)                   # a runt
+    blob += b"\x00" * 5
+    g = group_by_format(np.frombuffer(bytes(blob), dtype=np.uint8), offs, lens)
+    assert sorted(k for k in g if k is not None) == sorted(set(fmts))
+    assert g["%d"].tolist() == [0, 2, 5] and g["%af"].tolist() == [3]
+    assert g["%d %uld %lf %s %auc"].tolist() == [1, 4] and g[None].tolist() == [6]
