@@ -369,3 +369,82 @@ def IntegerPercentiles(ipackets, state=None, shape=W.SHAPE_TREE):
 
 FR_RANGE_MAX, FR_BINS = 1000, 20      # Examples/FaultRecovery/FaultRecovery.h:12-13
 PROT_WAVE = 102                       # FirstApplicationTag + 2 in that example's protocol enum (:17-19)
+
+
+class Filter:
+    """Filter::push_Packets for waves (src/Filter.C:24-131).  `func` follows the plugin calling
+    convention of src/Filter.h:64-68 reduced to what a wave needs --
+    func(ipackets, state, params) -> (list of output waves, new state) -- or is None, the NULL
+    filter, which hands the input wave on untouched (src/Filter.C:51-58).  The filter state lives
+    in the Filter between waves (void **filter_state there), parameters are a packet set with
+    set_FilterParams (src/Filter.C:133-137), get_FilterState asks the optional state function for
+    the state as a packet (src/Filter.C:119-131)."""
+
+    def __init__(self, func=None, get_state=None):
+        self._func, self._get_state = func, get_state
+        self._state, self._params = None, None
+
+    def set_FilterParams(self, params):
+        self._params = params
+
+    def push_Packets(self, ipackets):
+        if self._func is None:
+            return [ipackets]
+        out, self._state = self._func(ipackets, self._state, self._params)
+        return [p for p in out if p is not None]
+
+    def get_FilterState(self, stream_id):
+        if self._get_state is None:
+            return None                                   # Packet::NullPacket
+        return self._get_state(self._state, stream_id)
+
+
+def _stateless(fn):
+    return lambda ipackets, state, params: ([fn(ipackets)], state)
+
+
+def _perfdata(ipackets, state, params):
+    """tfilter_PerfData reads its aggregation id from the filter parameters, a '%d' packet
+    (src/FilterDefinitions.C:925-935)."""
+    if params is None:
+        return [], state
+    aggr = int(W.Codec.to_numpy(params.unpack("%d")[0].values).view(np.int32)[0])
+    return [tfilter_PerfData(ipackets, aggr)], state
+
+
+def _percentiles(ipackets, state, params):
+    # kept between waves: (the 16 state bytes on the device, the codec that owns them)
+    out, bits = IntegerPercentiles(ipackets, state[0] if state else None)
+    return [out], (bits, ipackets.codec)
+
+
+def _percentiles_state(state, stream_id):
+    """IntegerPercentiles_get_state (Examples/FaultRecovery/FaultRecoveryFilter.C:88-105): the
+    state as a '%uld %ud %ud' packet tagged PROT_WAVE on the asking stream."""
+    if state is None or state[0] is None:
+        return None
+    pk = PacketWave.__new__(PacketWave)
+    state, pk.codec = state
+    pk.fmt, pk.n = W.Format("%uld %ud %ud"), 1
+    pk.stream_id, pk.tag = stream_id, PROT_WAVE
+    pk.src_rank, pk.src_ranks, pk.inlet_rank = W.UNKNOWN_RANK, None, W.UNKNOWN_RANK
+    pk._hdrs, pk._error, pk.byteorder = None, False, W.LITTLEENDIAN
+    pk.wire = W.WireWave(state.clone(), 1, None, None, 16)
+    pk.columns, pk.ok, pk._decoded = None, None, False
+    return pk
+
+
+# the built-in transformation filters by name (ids are handed out at registration in the
+# reference, src/FilterDefinitions.C:28-56, so names are what is stable)
+BUILTIN_FILTERS = {
+    "TFILTER_NULL": lambda: Filter(None),
+    "TFILTER_SUM": lambda: Filter(_stateless(tfilter_Sum)),
+    "TFILTER_AVG": lambda: Filter(_stateless(tfilter_Avg)),
+    "TFILTER_MIN": lambda: Filter(_stateless(tfilter_Min)),
+    "TFILTER_MAX": lambda: Filter(_stateless(tfilter_Max)),
+    "TFILTER_ARRAY_CONCAT": lambda: Filter(_stateless(tfilter_ArrayConcat)),
+    "TFILTER_INT_EQ_CLASS": lambda: Filter(_stateless(tfilter_IntEqClass)),
+    "TFILTER_PERFDATA": lambda: Filter(_perfdata),
+    "IntegerPercentiles": lambda: Filter(_percentiles, _percentiles_state),
+    "BitsetOr": lambda: Filter(_stateless(BitsetOr)),
+}

@@ -214,3 +214,43 @@ def test_dynamic_filters(codec, num_backends):
     assert int(W.Codec.to_numpy(c3[0].values).view(np.uint8)[0]) == (200 * n) % 256
     assert int(W.Codec.to_numpy(c3[1].values).view(np.int16)[0]) == np.int16((-30000 * n + 32768) % 65536 - 32768)
     assert float(W.Codec.to_numpy(c3[2].values).view(np.float64)[0]) == 0.5 * n
+
+
+def test_filter_objects(codec):
+    """Filter::push_Packets (src/Filter.C:42-117): the NULL filter hands the wave on, a stateless
+    filter emits one packet, PerfData takes its aggregation from the parameter packet, and a
+    stateful filter carries its state from wave to wave and reports it through get_FilterState."""
+    from mrnet_amd.packet import BUILTIN_FILTERS
+    n = 300
+    vals = (np.arange(n, dtype=np.int32) * 3) % 17
+    wave = PacketWave(codec, 5, 100, "%d", [vals])
+    assert BUILTIN_FILTERS["TFILTER_NULL"]().push_Packets(wave) == [wave]
+    out = BUILTIN_FILTERS["TFILTER_SUM"]().push_Packets(wave)
+    assert len(out) == 1 and int(W.Codec.to_numpy(out[0].unpack("%d")[0].values).view(np.int32)[0]) == int(vals.sum())
+    assert BUILTIN_FILTERS["TFILTER_AVG"]().push_Packets(wave) == []          # "%d" is not an Avg format
+    # PerfData: aggregation id in the parameter packet
+    ranks = (np.ones(4, np.uint64), np.arange(4, dtype=np.int32))
+    nel = (np.ones(4, np.uint64), np.full(4, 2, np.int32))
+    data = (np.full(4, 2, np.uint64), np.arange(8, dtype=np.float64))
+    perf = PacketWave(codec, 5, 100, "%ad %ad %alf", [ranks, nel, data])
+    f = BUILTIN_FILTERS["TFILTER_PERFDATA"]()
+    assert f.push_Packets(perf) == []                                         # no parameters yet
+    f.set_FilterParams(PacketWave(codec, 5, 100, "%d", [np.array([W.TFILTER_MAX], np.int32)]))
+    got = f.push_Packets(perf)[0].unpack("%ad %ad %alf")
+    assert W.Codec.to_numpy(got[2].values).view(np.float64)[:2].tolist() == [6.0, 7.0]
+    assert int(W.Codec.to_numpy(got[0].values).view(np.int32)[0]) == -4
+    # a stateful filter: two waves through one Filter object
+    fp = BUILTIN_FILTERS["IntegerPercentiles"]()
+    assert fp.get_FilterState(5) is None
+
+    def bins(b, mx, mn):
+        return PacketWave(codec, 5, 102, "%uld %ud %ud", [np.array(b, np.uint64), np.array(mx, np.uint32),
+                                                          np.array(mn, np.uint32)])
+    o1 = fp.push_Packets(bins([1, 4], [10, 30], [5, 7]))[0].unpack("%uld %ud %ud")
+    assert [int(W.Codec.to_numpy(c.values).view(dt)[0]) for c, dt in zip(o1, (np.uint64, np.uint32, np.uint32))] == [5, 30, 5]
+    o2 = fp.push_Packets(bins([8], [20], [2]))[0].unpack("%uld %ud %ud")
+    assert [int(W.Codec.to_numpy(c.values).view(dt)[0]) for c, dt in zip(o2, (np.uint64, np.uint32, np.uint32))] == [13, 30, 2]
+    st = fp.get_FilterState(9)
+    assert st.get_StreamId() == 9 and st.get_Tag() == 102
+    sc = st.unpack("%uld %ud %ud")
+    assert [int(W.Codec.to_numpy(c.values).view(dt)[0]) for c, dt in zip(sc, (np.uint64, np.uint32, np.uint32))] == [13, 30, 2]
