@@ -142,3 +142,29 @@ def test_mixed_orders_large_arrays(codec):
     dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, offs, lens), codec.to_device(orders))
     assert bool(ok.all())
     assert columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_garbage(codec, seed):
+    """Packets of random bytes (length prefixes of any size, zero string lengths, counts beyond the
+    packet): the per-packet verdicts and whatever decoded before the first bad field must equal the
+    oracle's, and nothing may be read or written outside the buffers."""
+    fmt_s, n, _, _, _ = draw(7000 + seed)
+    n = max(n, 64)
+    r = splitmix64(900 + seed, n)
+    lens = (r % np.uint64(120)).astype(np.uint64)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(lens + np.uint64(3), out=offs[1:])
+    arena = (splitmix64(901 + seed, int(offs[n]) + 8) & np.uint64(0xFF)).astype(np.uint8)
+    if seed % 3 == 0:
+        # mostly small numbers, so that some prefixes are plausible and decoding gets further
+        arena[(splitmix64(902 + seed, arena.size) % np.uint64(4)) != 0] = 0
+    bo = W.BIGENDIAN if seed % 2 else W.LITTLEENDIAN
+    ref_cols, ref_ok = O.wave_decode(fmt_s, arena, offs, lens, bo)
+    fmt = W.Format(fmt_s)
+    if fmt.is_fixed:
+        return                                       # scalar-only formats have no prefixes to corrupt
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, arena, offs, lens), bo)
+    assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
+    assert columns_equal(host_cols(fmt, dcols, n), ref_cols), fmt_s
+    assert codec.status() == 0
