@@ -254,7 +254,7 @@ def header_decode(hdr):
     if not ok:
         return None
     return {"stream_id": sid.value, "tag": tag.value, "src_rank": src.value,
-            "fmt": fmt.value.decode(), "dest": dest[: nd.value].copy(), "byteorder": bo.value}
+            "fmt": fmt.value.decode("latin-1"), "dest": dest[: nd.value].copy(), "byteorder": bo.value}
 
 
 def byte_swap(a, elsize):

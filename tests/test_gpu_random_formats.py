@@ -168,3 +168,43 @@ def test_random_garbage(codec, seed):
     assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
     assert columns_equal(host_cols(fmt, dcols, n), ref_cols), fmt_s
     assert codec.status() == 0
+
+
+def test_random_garbage_headers(codec):
+    """Headers of random bytes, and good headers with one byte damaged: ok[i] must be set exactly
+    when the oracle's header decode succeeds with the expected format string."""
+    fmt_s = "%d %s"
+    fmt = W.Format(fmt_s)
+    good = O.header_encode(77, 101, 5, fmt_s)
+    n = 600
+    hl = good.size + 9
+    rows = np.zeros((n, hl), dtype=np.uint8)
+    lens = np.zeros(n, dtype=np.uint64)
+    r = splitmix64(4242, n * 4).reshape(n, 4)
+    for i in range(n):
+        kind = int(r[i, 0] % np.uint64(4))
+        if kind == 0:                                # random bytes, random length
+            l = int(r[i, 1] % np.uint64(hl + 1))
+            rows[i, :l] = (splitmix64(int(r[i, 2] % np.uint64(1 << 30)), l) & np.uint64(0xFF)).astype(np.uint8)
+        elif kind == 1:                              # good header, one byte damaged
+            l = good.size
+            rows[i, :l] = good
+            rows[i, int(r[i, 1] % np.uint64(l))] ^= np.uint8(1 + int(r[i, 2] % np.uint64(255)))
+        elif kind == 2:                              # good header, cut short or padded
+            l = int(r[i, 1] % np.uint64(hl + 1))
+            rows[i, :good.size] = good
+        else:
+            l = good.size
+            rows[i, :l] = good
+        lens[i] = l
+    want = np.zeros(n, dtype=np.int32)
+    for i in range(n):
+        d = O.header_decode(rows[i, :int(lens[i])]) if lens[i] else None
+        want[i] = int(d is not None and d["fmt"] == fmt_s)
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(hl))
+    out = codec.decode_headers(fmt, n, codec.to_device(rows.reshape(-1)), offsets=codec.to_device(offs),
+                               lens=codec.to_device(lens), max_dest=4)
+    got = W.Codec.to_numpy(out["ok"])
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad[:5], [(rows[i, :int(lens[i])].tobytes().hex(), int(want[i])) for i in bad[:3]])
+    assert want.sum() > n // 8
