@@ -430,8 +430,6 @@ static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t a
     if (n) {
         k_scan_partial<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, phase, c->tile_sums);
         LAUNCHED("k_scan_partial");
-        k_scan_top<<<1, MRPDR_TPB, 0, st>>>(c->tile_sums, tiles);
-        LAUNCHED("k_scan_top");
     }
     k_scan_final<<<tiles, MRPDR_TPB, 0, st>>>(in, n, align, phase, c->tile_sums, out);
     LAUNCHED("k_scan_final");

@@ -67,25 +67,17 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_partial(const uint64_t *in, 
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-// Pass 2: one workgroup turns the tile sums into exclusive prefixes, in place.
-__global__ __launch_bounds__(MRPDR_TPB) void k_scan_top(uint64_t *tile_sums, uint64_t ntiles)
-{
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < ntiles; base += MRPDR_TPB) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t v = i < ntiles ? tile_sums[i] : 0;
-        uint64_t total;
-        const uint64_t ex = block_exclusive_scan(v, &total);
-        if (i < ntiles) tile_sums[i] = carry + ex;
-        carry += total;
-    }
-}
-
-// Pass 3: offsets[i] = prefix of tile + scan inside the tile; offsets[n] = grand total.
+// Pass 2: offsets[i] = sums of the tiles in front (a few thousand at most, added up by the
+// workgroup itself: cheaper than a launch in between that scans them) + scan inside the tile;
+// offsets[n] = grand total.
 __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, uint64_t n, uint32_t align,
-                                                          uint32_t phase, const uint64_t *tile_prefix,
+                                                          uint32_t phase, const uint64_t *tile_sums,
                                                           uint64_t *out)
 {
+    uint64_t before = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += MRPDR_TPB) before += tile_sums[j];
+    uint64_t tile_base;
+    block_exclusive_scan(before, &tile_base);
     const uint64_t first = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_IPT;
     uint64_t v[SCAN_IPT];
     uint64_t s = 0;
@@ -95,7 +87,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, ui
         s += v[k];
     }
     uint64_t total;
-    uint64_t run = tile_prefix[blockIdx.x] + block_exclusive_scan(s, &total);
+    uint64_t run = tile_base + block_exclusive_scan(s, &total);
 #pragma unroll
     for (int k = 0; k < SCAN_IPT; k++) {
         if (first + k < n) out[first + k] = run + phase;
@@ -110,7 +102,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, ui
 // but computed from the wave's count columns -- the pdr_sizeof dry run of every packet
 // (src/pdr_sizeof.c:120-140) -- and also stored to lens[].
 #define SCAN1_TPB 1024
-#define SCAN1_MAX_N (4u * SCAN1_TPB * SCAN_IPT)     // above this the three-pass scan is faster
+#define SCAN1_MAX_N (4u * SCAN1_TPB * SCAN_IPT)     // above this the two-launch scan is faster
 
 template <bool SIZED>
 __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, FmtDev fmt, ColsDev cols,
