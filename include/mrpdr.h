@@ -141,9 +141,10 @@ int32_t     mrpdr_local_byteorder(void);
  * every later call with this ctx. */
 mrpdr_ctx  *mrpdr_ctx_create(int32_t device, uint64_t max_packets);
 void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
-/* Sticky device-side status: 0 = fine, bit 0 = a decode (or array filter) ran out of column capacity
- * (values or, for string arrays, sub_counts / sub_offs).
- * Synchronises `stream`. */
+/* Device-side status, accumulated over the calls made with this ctx since it was last read:
+ * 0 = fine, bit 0 = a decode (or array filter) ran out of column capacity (values or, for string
+ * arrays, sub_counts / sub_offs), bit 1 = an array concatenation reached 2^32 elements.
+ * Reading clears it.  Synchronises `stream`. */
 int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
 
 /* Timing of the payload kernels, the counterpart of the reference's per-filter / per-packet

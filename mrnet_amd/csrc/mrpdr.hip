@@ -278,6 +278,7 @@ extern "C" int32_t mrpdr_ctx_status(mrpdr_ctx *c, void *stream, uint32_t *status
 {
     if (!c || !status_host) return fail("mrpdr_ctx_status: NULL argument");
     HIP_OK(hipMemcpyAsync(status_host, c->status, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_OK(hipMemsetAsync(c->status, 0, sizeof(uint32_t), (hipStream_t)stream));     // read and clear
     HIP_OK(hipStreamSynchronize((hipStream_t)stream));
     return 1;
 }

@@ -36,6 +36,14 @@ def draw(seed):
     return fmt, n, max_count, align, phase
 
 
+def blank_like(cols):
+    """Columns of the same capacities, filled with a pattern."""
+    def blank(t):
+        return None if t is None else torch.full_like(t, 0x5A)
+    return [W.Column(blank(c.values), blank(c.counts), blank(c.offs), c.capacity, blank(c.sub_counts),
+                     blank(c.sub_offs), c.sub_capacity) for c in cols]
+
+
 @pytest.mark.parametrize("seed", range(120))
 def test_random_format_round_trip(codec, seed):
     fmt_s, n, max_count, align, phase = draw(1000 + seed)
@@ -64,6 +72,13 @@ def test_random_format_round_trip(codec, seed):
     assert bool(ok.all()) if n else True
     assert columns_equal(host_cols(fmt, dcols, n), ocols), (fmt_s, n, bo)
     assert codec.status() == 0
+    # the one-call form into columns the caller sized (no totals read back in between)
+    cols2 = blank_like(dcols)
+    ok2 = torch.zeros_like(ok)
+    codec.decode_into(fmt, wire_from_numpy(codec, n, src, offs, lens), cols2, ok2, bo)
+    assert torch.equal(ok2, ok)
+    assert columns_equal(host_cols(fmt, cols2, n), ocols), (fmt_s, n, bo, "decode_into")
+    assert codec.status() == 0
 
 
 @pytest.mark.parametrize("seed", range(40))
@@ -89,6 +104,10 @@ def test_random_truncation(codec, seed):
     dcols, ok = codec.decode(fmt, wire, bo)
     assert np.array_equal(W.Codec.to_numpy(ok), ref_ok), fmt_s
     assert columns_equal(host_cols(fmt, dcols, n), ref_cols), fmt_s
+    cols2 = blank_like(dcols)
+    ok2 = torch.zeros_like(ok)
+    codec.decode_into(fmt, wire, cols2, ok2, bo)
+    assert torch.equal(ok2, ok) and columns_equal(host_cols(fmt, cols2, n), ref_cols), (fmt_s, "decode_into")
 
 
 def mixed_arena(fmt_s, arena, offs, lens, orders):
@@ -208,3 +227,30 @@ def test_random_garbage_headers(codec):
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, (bad[:5], [(rows[i, :int(lens[i])].tobytes().hex(), int(want[i])) for i in bad[:3]])
     assert want.sum() > n // 8
+
+
+@pytest.mark.parametrize("fmt_s,n,max_count,field", [
+    ("%d %s %auc", 500, 30, 2),           # short packets: tile kernels
+    ("%af", 6, 100000, 0),                # long arrays: chunk kernel
+    ("%ahd %ad", 3000, 900, 1),           # mid-size payloads, two fields
+    ("%d %as", 200, 5, 1),                # string arrays: bytes
+    ("%auc %auc %auc %auc %auc %auc %auc %auc %auc", 300, 20, 8),   # more variable fields than a tile takes
+])
+def test_decode_into_columns_too_small(codec, fmt_s, n, max_count, field):
+    """The one-call decode into columns that cannot hold the wave: nothing is written to the
+    column that is too small, the status word says so, and reading it clears it."""
+    counts = {0: np.full(n, max_count, np.uint64)} if fmt_s == "%af" else None
+    ocols = make_wave(fmt_s, n, 3, max_count=max_count, counts=counts)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    fmt = W.Format(fmt_s)
+    wire = wire_from_numpy(codec, n, arena, offs, lens)
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert codec.status() == 0
+    cols2 = blank_like(dcols)
+    cols2[field].capacity = int(dcols[field].capacity) - 1
+    guard = cols2[field].values.clone()
+    ok2 = torch.zeros_like(ok)
+    codec.decode_into(fmt, wire, cols2, ok2, W.LITTLEENDIAN)
+    assert codec.status() & 1
+    assert torch.equal(cols2[field].values, guard)
+    assert codec.status() == 0                      # read and cleared

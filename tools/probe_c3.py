@@ -5,7 +5,8 @@ import torch
 from mrnet_amd import wave as W
 import bench
 codec = W.Codec(max_packets=1 << 18)
-st = bench.ArrayWaveStep(codec, 4096, 65536, 3)
+n, m = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (4096, 65536)
+st = bench.ArrayWaveStep(codec, n, m, 3)
 for _ in range(3):
     st.step()
 parts = {
