@@ -70,6 +70,21 @@ __device__ inline uint64_t var_bytes(const FmtDev &fmt, const ColsDev &cols, int
     return 4 * cnt + (cols.sub_offs[g][first + cnt] - cols.sub_offs[g][first]);
 }
 
+// pdr_sizeof of packet i: the fixed part plus the payloads of its variable fields
+// (src/pdr_sizeof.c:120-140 over Packet::pdr_packet_data).  A '%s' field without a single byte
+// -- not even the NUL -- stands for the NULL pointer, which pdr_string refuses to encode
+// (src/pdr.c:279-282): such a packet has no valid encoding and sets *bad.
+__device__ inline uint64_t packet_bytes(const FmtDev &fmt, const ColsDev &cols, uint64_t i, bool *bad)
+{
+    uint64_t len = fmt.fixed_bytes;
+    for (int f = 0; f < fmt.nf; f++) {
+        if (fmt.f[f].kind == MRPDR_SCALAR) continue;
+        len += var_bytes(fmt, cols, f, i);
+        if (fmt.f[f].kind == MRPDR_STRING && cols.counts[f][i] == 0) *bad = true;
+    }
+    return len;
+}
+
 __device__ inline uint64_t pkt_off(const WireDev &w, uint64_t i)
 {
     return w.offsets ? w.offsets[i] : i * w.stride;

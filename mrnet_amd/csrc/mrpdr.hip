@@ -423,7 +423,7 @@ static int32_t run_scan(mrpdr_ctx *c, const uint64_t *in, uint64_t n, uint32_t a
                         uint64_t *out, hipStream_t st)
 {
     if (n <= SCAN1_MAX_N) {
-        k_scan_single<false><<<1, SCAN1_TPB, 0, st>>>(in, FmtDev(), ColsDev(), n, align, phase, nullptr, out);
+        k_scan_single<false><<<1, SCAN1_TPB, 0, st>>>(in, FmtDev(), ColsDev(), n, align, phase, nullptr, out, nullptr);
         LAUNCHED("k_scan_single");
         return 1;
     }
@@ -490,11 +490,11 @@ extern "C" int32_t mrpdr_wave_sizeof(mrpdr_ctx *c, const mrpdr_fmt *f, const mrp
     if (!fill_cols("mrpdr_wave_sizeof", f, cols, n, false, &cd)) return 0;
     if (n <= SCAN1_MAX_N) {
         // sizing and scan fused in one launch
-        k_scan_single<true><<<1, SCAN1_TPB, 0, st>>>(nullptr, f->dev, cd, n, align, phase, lens, offsets);
+        k_scan_single<true><<<1, SCAN1_TPB, 0, st>>>(nullptr, f->dev, cd, n, align, phase, lens, offsets, c->status);
         LAUNCHED("k_scan_single");
     } else {
         const uint32_t blocks = blocks_for(n, SIZE_PKTS);
-        k_size_sums<<<blocks, MRPDR_TPB, 0, st>>>(f->dev, cd, n, align, phase, lens, c->tile_sums);
+        k_size_sums<<<blocks, MRPDR_TPB, 0, st>>>(f->dev, cd, n, align, phase, lens, c->tile_sums, c->status);
         LAUNCHED("k_size_sums");
         k_size_offs<<<blocks, MRPDR_TPB, 0, st>>>(lens, n, align, phase, c->tile_sums, offsets);
         LAUNCHED("k_size_offs");

@@ -18,19 +18,6 @@
 #define ROWS_MAX_STRIDE 256
 
 // ---------------------------------------------------------------------------
-// sizing of variable-length packets (encode side): the pdr_sizeof dry run
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(MRPDR_TPB) void k_size(FmtDev fmt, ColsDev cols, uint64_t n, uint64_t *lens)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= n) return;
-    uint64_t len = fmt.fixed_bytes;
-    for (int f = 0; f < fmt.nf; f++)
-        if (fmt.f[f].kind != MRPDR_SCALAR) len += var_bytes(fmt, cols, f, i);
-    lens[i] = len;
-}
-
-// ---------------------------------------------------------------------------
 // LDS-staged transposition, scalar-only formats, packed arena
 // ---------------------------------------------------------------------------
 template <bool SWAP>

@@ -107,9 +107,10 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_scan_final(const uint64_t *in, ui
 template <bool SIZED>
 __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, FmtDev fmt, ColsDev cols,
                                                            uint64_t n, uint32_t align, uint32_t phase,
-                                                           uint64_t *lens, uint64_t *out)
+                                                           uint64_t *lens, uint64_t *out, uint32_t *status)
 {
     uint64_t carry = 0;
+    bool bad = false;
     for (uint64_t base = 0; base < n; base += (uint64_t)SCAN1_TPB * SCAN_IPT) {
         const uint64_t first = base + (uint64_t)threadIdx.x * SCAN_IPT;
         uint64_t v[SCAN_IPT];
@@ -119,9 +120,7 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
             uint64_t item = 0;
             if (first + k < n) {
                 if (SIZED) {
-                    item = fmt.fixed_bytes;
-                    for (int f = 0; f < fmt.nf; f++)
-                        if (fmt.f[f].kind != MRPDR_SCALAR) item += var_bytes(fmt, cols, f, first + k);
+                    item = packet_bytes(fmt, cols, first + k, &bad);
                     lens[first + k] = item;
                 } else {
                     item = in[first + k];
@@ -141,6 +140,7 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
         carry += total;
     }
     if (threadIdx.x == 0) out[n] = carry;
+    if (SIZED && bad) atomicOr(status, 4u);
 }
 
 // Larger waves, sizing + offsets in TWO launches: every workgroup sizes SIZE_PKTS packets and
@@ -149,19 +149,20 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
 #define SIZE_PKTS (MRPDR_TPB * 4)
 
 __global__ __launch_bounds__(MRPDR_TPB) void k_size_sums(FmtDev fmt, ColsDev cols, uint64_t n, uint32_t align,
-                                                         uint32_t phase, uint64_t *lens, uint64_t *sums)
+                                                         uint32_t phase, uint64_t *lens, uint64_t *sums,
+                                                         uint32_t *status)
 {
+    bool bad = false;
     const uint64_t first = (uint64_t)blockIdx.x * SIZE_PKTS + (uint64_t)threadIdx.x * 4;
     uint64_t s = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (first + k >= n) break;
-        uint64_t item = fmt.fixed_bytes;
-        for (int f = 0; f < fmt.nf; f++)
-            if (fmt.f[f].kind != MRPDR_SCALAR) item += var_bytes(fmt, cols, f, first + k);
+        const uint64_t item = packet_bytes(fmt, cols, first + k, &bad);
         lens[first + k] = item;
         s += round_up_pow2(item + phase, align);
     }
+    if (bad) atomicOr(status, 4u);
     uint64_t total;
     block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) sums[blockIdx.x] = total;

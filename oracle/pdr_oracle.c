@@ -538,8 +538,10 @@ static int32_t build_elems(orc_packet *pkt, const char *fmt, const orc_column *c
             e->val.p = (char *)c->values + c->offs[i] * (uint64_t)w;
             break;
         case 2:
-            e->val.p = (char *)c->values + c->offs[i];
-            e->array_len = c->counts[i] - 1;
+            /* a string without a single byte (not even the NUL) stands for the NULL pointer,
+             * which pdr_string refuses to encode (src/pdr.c:279-282) */
+            e->val.p = c->counts[i] ? (char *)c->values + c->offs[i] : NULL;
+            e->array_len = c->counts[i] ? c->counts[i] - 1 : 0;
             break;
         case 3: {
             uint64_t ns = c->counts[i], first = c->offs[i];

@@ -555,3 +555,19 @@ def test_column_beyond_four_gibibytes(codec):
             assert torch.equal(le.arena[p + 8:p + 8 + 4 * c].clone().view(torch.int32), vals[at:at + c])
         at += c
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("n", [5, 40000])
+def test_null_string_is_flagged_by_sizeof(codec, n):
+    """A '%s' field with no bytes at all stands for the NULL pointer pdr_string refuses to encode
+    (src/pdr.c:279-282): sizeof raises status bit 2; the empty string (one NUL) is fine."""
+    fmt = W.Format("%d %s")
+    cnt = np.full(n, 3, np.uint64)
+    cols = codec.columns_from_numpy(fmt, [np.arange(n, dtype=np.int32), (cnt, np.tile(np.frombuffer(b"hi\0", np.uint8), n))])
+    codec.sizeof(fmt, cols, n)
+    assert codec.status() == 0
+    cnt[n // 2] = 0
+    body = np.tile(np.frombuffer(b"hi\0", np.uint8), n - 1)
+    cols = codec.columns_from_numpy(fmt, [np.arange(n, dtype=np.int32), (cnt, body)])
+    codec.sizeof(fmt, cols, n)
+    assert codec.status() == 4

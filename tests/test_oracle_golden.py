@@ -318,3 +318,18 @@ def test_wave_decode_with_one_order_per_packet():
     # the wrong order for the foreign half: length prefixes read reversed, those packets fail
     _, ok_le = O.wave_decode(fmt, src, offs, lens, O.LITTLE)
     assert np.array_equal(ok_le != 0, orders == 0)
+
+
+def test_null_string_cannot_be_encoded():
+    """pdr_string refuses a NULL pointer on encode (src/pdr.c:279-282); in column form that is a
+    '%s' field without a single byte."""
+    cols = [{"type": O.fmt_types("%d %s")[0], "values": np.array([1, 2], np.int32)},
+            {"type": O.fmt_types("%d %s")[1], "counts": np.array([3, 0], np.uint64),
+             "offs": np.array([0, 3, 3], np.uint64), "values": np.frombuffer(b"hi\0", dtype=np.uint8).copy()}]
+    with pytest.raises(RuntimeError):
+        O.wave_sizeof("%d %s", cols, 2)
+    cols[1]["counts"] = np.array([3, 1], np.uint64)           # the empty string "" is fine: one NUL byte
+    cols[1]["offs"] = np.array([0, 3, 4], np.uint64)
+    cols[1]["values"] = np.frombuffer(b"hi\0\0", dtype=np.uint8).copy()
+    arena, offs, lens = O.wave_encode("%d %s", cols, 2)
+    assert lens.tolist() == [4 + 4 + 3, 4 + 4 + 1]
