@@ -144,9 +144,10 @@ void        mrpdr_ctx_destroy(mrpdr_ctx *ctx);
 /* Device-side status, accumulated over the calls made with this ctx since it was last read:
  * 0 = fine, bit 0 = a decode (or array filter) ran out of column capacity (values or, for string
  * arrays, sub_counts / sub_offs), bit 1 = an array concatenation reached 2^32 elements,
- * bit 2 = mrpdr_wave_sizeof met a '%s' field of count 0 (no bytes at all, not even the NUL):
- * the NULL string that pdr_string refuses to encode (src/pdr.c:279-282); that packet's bytes
- * are not a valid packet.  Reading clears it.  Synchronises `stream`. */
+ * bit 2 = mrpdr_wave_sizeof met a packet the reference refuses to encode: a '%s' field of
+ * count 0 (no bytes at all, not even the NUL: the NULL string, src/pdr.c:279-282), or a '%a'
+ * array of more than INT32_MAX elements (src/pdr.c:429; '%A' has no bound); that packet's
+ * bytes are not a valid packet.  Reading clears it.  Synchronises `stream`. */
 int32_t     mrpdr_ctx_status(mrpdr_ctx *ctx, void *stream, uint32_t *status_host);
 
 /* Timing of the payload kernels, the counterpart of the reference's per-filter / per-packet

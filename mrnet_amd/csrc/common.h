@@ -73,14 +73,20 @@ __device__ inline uint64_t var_bytes(const FmtDev &fmt, const ColsDev &cols, int
 // pdr_sizeof of packet i: the fixed part plus the payloads of its variable fields
 // (src/pdr_sizeof.c:120-140 over Packet::pdr_packet_data).  A '%s' field without a single byte
 // -- not even the NUL -- stands for the NULL pointer, which pdr_string refuses to encode
-// (src/pdr.c:279-282): such a packet has no valid encoding and sets *bad.
+// (src/pdr.c:279-282), and so are counts beyond the token's bound: such a packet has no valid
+// encoding and sets *bad.
 __device__ inline uint64_t packet_bytes(const FmtDev &fmt, const ColsDev &cols, uint64_t i, bool *bad)
 {
     uint64_t len = fmt.fixed_bytes;
     for (int f = 0; f < fmt.nf; f++) {
         if (fmt.f[f].kind == MRPDR_SCALAR) continue;
         len += var_bytes(fmt, cols, f, i);
-        if (fmt.f[f].kind == MRPDR_STRING && cols.counts[f][i] == 0) *bad = true;
+        const uint64_t cnt = cols.counts[f][i];
+        if (fmt.f[f].kind == MRPDR_STRING) {
+            if (cnt == 0 || cnt > 0xFFFFFFFEull) *bad = true;      // NULL, or beyond pdr_wrapstring's bound (src/pdr.c:291,332)
+        } else if (!fmt.f[f].large && cnt > (uint64_t)INT32_MAX) {
+            *bad = true;                                           // '%a' counts stop at INT32_MAX (src/pdr.c:429, src/Packet.C:647-810)
+        }
     }
     return len;
 }

@@ -571,3 +571,18 @@ def test_null_string_is_flagged_by_sizeof(codec, n):
     cols = codec.columns_from_numpy(fmt, [np.arange(n, dtype=np.int32), (cnt, body)])
     codec.sizeof(fmt, cols, n)
     assert codec.status() == 4
+
+
+def test_array_count_bound_is_flagged_by_sizeof(codec):
+    """'%a' arrays stop at INT32_MAX elements (pdr_array's maxsize, src/pdr.c:429 with
+    src/Packet.C:647-810); '%A' arrays do not.  sizeof reads only the counts."""
+    n = 3
+    big = np.array([1, 2**31 + 5, 2], np.uint64)
+    for fmt_s, want in (("%auc", 4), ("%Auc", 0)):
+        fmt = W.Format(fmt_s)
+        cols = codec.alloc_columns(fmt, n, capacities=[16])
+        cols[0].counts = codec.to_device(big)
+        cols[0].offs = codec.to_device(np.concatenate([[0], np.cumsum(big)]).astype(np.uint64))
+        lens, offs, total = codec.sizeof(fmt, cols, n)
+        assert total == 3 * 8 + int(big.sum())
+        assert codec.status() == want
