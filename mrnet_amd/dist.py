@@ -52,3 +52,55 @@ def filter_wire_sharded(codec, op, fmt, wire, sender_bo=W.LITTLEENDIAN, group=No
     res, ok = codec.filter_wire(op, fmt, wire, sender_bo, W.SHAPE_TREE)
     rows, oks = gather_results(res, ok, group)
     return combine_results(codec, op, fmt.types[0], fmt.widths[0], rows, oks)
+
+
+# ---- tfilter_PerfData across ranks ---------------------------------------------------------
+# Every rank folds its shard into one output packet ([-nranks], [len], data[len]); the packets of
+# all ranks are gathered and folded once more by the same filter, in rank order -- the per-GPU
+# results are the children of the root of the tree (src/FilterDefinitions.C:904-1239 runs at
+# every level).  The exchange is one all_gather of 16 + 8*cap bytes per rank.
+
+def pack_perfdata(out_data, out_len, out_rank, cap):
+    """One rank's output packet as a fixed-size row: i32 rank | i32 pad | i64 len | cap x 8 bytes."""
+    row = torch.zeros(16 + 8 * cap, dtype=torch.uint8, device=out_data.device)
+    row[0:4] = out_rank.view(torch.uint8)[:4]
+    row[8:16] = out_len.view(torch.uint8)[:8]
+    row[16:] = out_data.view(torch.uint8)[:8 * cap]
+    return row
+
+
+def gather_rows(row, group=None):
+    """all_gather of equal-size byte rows, rank order (on the device with RCCL, via the host
+    with gloo)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return row.view(1, -1).clone()
+    dev = row.device
+    send = row.cpu() if row.is_cuda and dist.get_backend(group) == "gloo" else row
+    out = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(out, send, group=group)
+    return torch.stack(out).to(dev)
+
+
+def unpack_perfdata(rows, cap):
+    """Gathered rows -> the rank and data columns of a wave of len(rows) packets: the ranks are
+    packed, the data arrays keep their row positions (offs = g * cap)."""
+    g = rows.shape[0]
+    dev = rows.device
+    ranks = rows[:, 0:4].contiguous().view(torch.int32).view(-1)
+    lens = rows[:, 8:16].contiguous().view(torch.int64).view(-1)
+    data = rows[:, 16:].contiguous().view(torch.int64).view(-1)
+    ones = torch.ones(g, dtype=torch.int64, device=dev)
+    rank_col = W.Column(ranks, ones, torch.arange(g + 1, dtype=torch.int64, device=dev), g)
+    data_col = W.Column(data, lens, torch.arange(g + 1, dtype=torch.int64, device=dev) * cap, g * cap)
+    return rank_col, data_col
+
+
+def perfdata_sharded(codec, op, dtype, ranks, data, n, cap, group=None):
+    """tfilter_PerfData over a wave spread over the ranks of `group`; ranks / data are this rank's
+    decoded columns (n packets), cap bounds the result length.  Every rank returns the same
+    (out_data, out_len, out_rank)."""
+    out, out_len, out_rank = codec.filter_perfdata(op, dtype, ranks, data, n, out_cap=cap)
+    rows = gather_rows(pack_perfdata(out, out_len, out_rank, cap), group)
+    rank_col, data_col = unpack_perfdata(rows, cap)
+    return codec.filter_perfdata(op, dtype, rank_col, data_col, rows.shape[0], out_cap=cap)

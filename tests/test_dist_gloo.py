@@ -91,3 +91,57 @@ def test_two_ranks_gather_and_ordered_fold():
         assert final is not None
         if op == O.MAX:
             assert final[0] == vals.max()
+
+
+def _perf_worker(rank, world, port, n, k, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rc, rv, dc, dv = _perf_wave(n, k)
+        lo, hi = D.shard_range(n, rank, world)
+        orank, odata = O.filter_perfdata(O.AVG, O.DOUBLE_T, (rc[lo:hi], rv[lo:hi]), (dc[lo:hi], dv[lo * k:hi * k]))
+        out = np.zeros(k, np.float64)
+        out[:odata.size] = odata
+        row = D.pack_perfdata(torch.from_numpy(out).view(torch.int64), torch.tensor([odata.size], dtype=torch.int64),
+                              torch.tensor([orank], dtype=torch.int32), k)
+        rows = D.gather_rows(row)
+        rank_col, data_col = D.unpack_perfdata(rows, k)
+        q.put((rank, rank_col.values.numpy().copy(), data_col.counts.numpy().copy(), data_col.offs.numpy().copy(),
+               data_col.values.numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _perf_wave(n, k):
+    rc = np.ones(n, np.uint64)
+    rv = np.arange(n, dtype=np.int32)
+    dc = np.full(n, k, np.uint64)
+    dv = (random_values(np.float64, n * k, 9) % 1000.0)
+    dv = np.where(np.isfinite(dv), dv, 1.0)
+    return rc, rv, dc, dv
+
+
+def test_two_ranks_perfdata_exchange():
+    """The per-rank PerfData packets are gathered in rank order, and folding them once more equals
+    the filter run as a two-level tree over the whole wave (fan-ins n/2, then 2)."""
+    world, n, k = 2, 1000, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_perf_worker, args=(r, world, port, n, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for a, b in zip(got[0][1:], got[1][1:]):
+        assert np.array_equal(a, b)                                   # every rank holds the same wave
+    _, ranks, lens, offs, data = got[0]
+    assert ranks.tolist() == [-(n // 2), -(n // 2)] and lens.tolist() == [k, k] and offs.tolist() == [0, k, 2 * k]
+    rc, rv, dc, dv = _perf_wave(n, k)
+    final = O.filter_perfdata(O.AVG, O.DOUBLE_T, (np.ones(2, np.uint64), ranks),
+                              (lens.astype(np.uint64), data.view(np.float64)[:2 * k]))
+    tree = O.filter_perfdata_tree(O.AVG, O.DOUBLE_T, (rc, rv), (dc, dv), [n // 2, 0])
+    assert final[0] == tree[0] == -n and np.array_equal(final[1].view(np.uint8), tree[1].view(np.uint8))
