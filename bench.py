@@ -280,6 +280,7 @@ def small_wave_extras(codec):
     out.update(perfdata_extra(codec))
     out.update(mixed_wave_extra(codec))
     out.update(batched_small_waves_extra(dev))
+    out.update(message_extra(codec))
     assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
     assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
     return out
@@ -370,6 +371,44 @@ def mixed_wave_extra(codec):
     res = {"c4_encode_us": round(t_enc * 1e6, 1), "c4_decode_us": round(t_dec * 1e6, 1),
            "c4_gbps": round(nbytes / (t_enc + t_dec) / 1e9, 1), "c4_wire_mib": round(data / 2**20, 1)}
     return res
+
+
+def message_extra(codec):
+    """The unit MRNet puts on a link (src/Message.C): config 2 and config 4 waves built as one
+    Message each (preamble + headers + data, encoded in place) and taken apart again (size vector,
+    headers, data).  Both include the host's read of the packet count / the payload size, as
+    Message::send / recv need them."""
+    out = {}
+    dev = codec.device
+    rng = np.random.default_rng(6)
+    n = 65536
+    waves = {"c2": (W.Format("%d"), [rng.integers(-2**31, 2**31, n).astype(np.int32)])}
+    slen = np.minimum(rng.geometric(1.0 / 12.0, n), 255).astype(np.uint64) + 1
+    alen = rng.integers(0, 513, n).astype(np.uint64)
+    sbody = rng.integers(33, 127, int(slen.sum()), dtype=np.uint8)
+    sbody[np.cumsum(slen).astype(np.int64) - 1] = 0
+    waves["c4"] = (W.Format("%d %uld %lf %s %auc"), [
+        rng.integers(-2**31, 2**31, n).astype(np.int32), rng.integers(0, 2**63, n).astype(np.uint64),
+        rng.uniform(-1e6, 1e6, n), (slen, sbody), (alen, rng.integers(0, 256, int(alen.sum()), dtype=np.uint8))])
+    for name, (fmt, host_cols) in waves.items():
+        cols = codec.columns_from_numpy(fmt, host_cols)
+        msg = codec.message_build(fmt, cols, n)
+
+        def build():
+            codec.message_build(fmt, cols, n)
+
+        def parse():
+            _, hdr, wire = codec.message_parse(fmt, msg)
+            codec.decode(fmt, wire)
+        tb, tp = time_call(build, 30), time_call(parse, 30)
+        _, hdr, wire = codec.message_parse(fmt, msg)
+        dcols, ok = codec.decode(fmt, wire)
+        assert bool(ok.all()) and bool(hdr["ok"].all())
+        assert torch.equal(dcols[0].values.view(torch.uint8), cols[0].values.view(torch.uint8))
+        out["f1_%s_message_build_us" % name] = round(tb * 1e6, 1)
+        out["f1_%s_message_parse_decode_us" % name] = round(tp * 1e6, 1)
+        out["f1_%s_message_mib" % name] = round(msg.numel() / 2**20, 1)
+    return out
 
 
 def time_call(fn, reps):
