@@ -586,3 +586,25 @@ def test_array_count_bound_is_flagged_by_sizeof(codec):
         lens, offs, total = codec.sizeof(fmt, cols, n)
         assert total == 3 * 8 + int(big.sum())
         assert codec.status() == want
+
+
+@pytest.mark.parametrize("fmt_s,n,max_count", [("%d", 65536, 0), ("%d %uld %lf %s %auc", 65536, 300),
+                                               ("%lf %d", 131072, 0), ("%ad %ad %alf", 131072, 8)])
+def test_baseline_configs_at_full_size(codec, fmt_s, n, max_count):
+    """The benchmark's wave shapes at their full packet counts, byte for byte against the oracle:
+    65,536 x '%d', 65,536 x the mixed format, one GPU's 131,072-packet shard of the '%lf %d' and
+    of the performance-data wave.  Encode, then decode what a big-endian sender would have sent."""
+    big = W.Codec(device=codec.device.index, max_packets=1 << 18)
+    ocols = make_wave(fmt_s, n, 17, max_count=max_count)
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    fmt = W.Format(fmt_s)
+    wire = big.encode(fmt, dev_cols(big, fmt, ocols), n)
+    assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
+    if not fmt.is_fixed:
+        assert np.array_equal(W.Codec.to_numpy(wire.lens).view(np.uint64), lens)
+    be = to_sender_order(fmt_s, arena, offs, lens)
+    src = wire_from_numpy(big, n, be, None, None, stride=fmt.fixed_bytes) if fmt.is_fixed \
+        else wire_from_numpy(big, n, be, offs, lens)
+    dcols, ok = big.decode(fmt, src, W.BIGENDIAN)
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
+    assert big.status() == 0
