@@ -5,7 +5,7 @@ probe=$1; shift
 for so in "$@"; do
   name=$(basename $so .so)
   rm -rf gpurun_out/var_$name
-  MRPDR_LIB=$so timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/var_$name -- python3 $probe > gpurun_out/var_$name.txt 2>&1 || exit 1
+  MRPDR_LIB=$so timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/var_$name -- python3 $probe > gpurun_out/var_$name.txt 2>&1; rc=$?; if [ $rc -gt 1 ]; then exit $rc; fi
   echo "== $name: $(grep -h encode gpurun_out/var_$name.txt | tail -1)"
   f=$(ls gpurun_out/var_$name/*/*kernel_stats.csv)
   python3 - "$f" <<'PY'
