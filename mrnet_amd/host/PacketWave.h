@@ -478,6 +478,11 @@ class PacketWave {
         hip_check(hipMemsetAsync(d_arena_.ptr<void>(), 0, d_arena_.bytes(), wc_.stream), "hipMemsetAsync");
         wire_ = mrpdr_wire{ d_arena_.ptr<uint8_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, total };
         if (!mrpdr_wave_encode(wc_.ctx, fmt_, cols_.data(), n_, &wire_, wc_.stream)) throw PdrError("mrpdr_wave_encode");
+        uint32_t status = 0;
+        if (!mrpdr_fmt_is_fixed(fmt_)) {
+            if (!mrpdr_ctx_status(wc_.ctx, wc_.stream, &status)) throw PdrError("mrpdr_ctx_status");
+            if (status) error_ = true;      // e.g. a NULL string: error(ERR_PACKING, ...), src/Packet.C:70-72
+        }
     }
 
     void encode_pdr_header(const std::vector<uint32_t> *src_ranks)      // src/Packet.C:20-52

@@ -47,6 +47,8 @@ class PacketWave:
         self._hdrs = None
         self.byteorder = W.LITTLEENDIAN
         self.wire = codec.encode(self.fmt, self.columns, n, align=align, phase=phase)   # encode_pdr_data
+        if not self.fmt.is_fixed and codec.status():
+            self._error = True      # e.g. a NULL string: error(ERR_PACKING, ...), src/Packet.C:70-72
 
     @classmethod
     def from_buffers(cls, codec, fmt, n, hdrs, hdr_stride, wire, inlet_rank=W.UNKNOWN_RANK):

@@ -254,3 +254,15 @@ def test_filter_objects(codec):
     assert st.get_StreamId() == 9 and st.get_Tag() == 102
     sc = st.unpack("%uld %ud %ud")
     assert [int(W.Codec.to_numpy(c.values).view(dt)[0]) for c, dt in zip(sc, (np.uint64, np.uint32, np.uint32))] == [13, 30, 2]
+
+
+def test_null_string_makes_the_packet_wave_erroneous(codec):
+    """Packet's constructor reports ERR_PACKING when encode_pdr_data fails (src/Packet.C:70-72), as
+    it does for a NULL string (src/pdr.c:279-282): a '%s' field without bytes."""
+    good = PacketWave(codec, 5, 100, "%d %s", [np.arange(3, dtype=np.int32),
+                                              (np.array([3, 1, 3], np.uint64), np.frombuffer(b"hi\0\0yo\0", np.uint8))])
+    assert not good.has_Error()
+    bad = PacketWave(codec, 5, 100, "%d %s", [np.arange(3, dtype=np.int32),
+                                             (np.array([3, 0, 3], np.uint64), np.frombuffer(b"hi\0yo\0", np.uint8))])
+    assert bad.has_Error()
+    assert codec.status() == 0
