@@ -235,9 +235,11 @@ int32_t orc_array(orc_stream *s, void **addrp, uint64_t *sizep, uint64_t maxsize
         case ORC_DECODE:
             if (c == 0) return 1;
             /* The reference callocs count*elsize before looking at the remaining
-             * space; a corrupt count would ask for petabytes.  Fail such packets
-             * up front: the element loop below would fail them anyway. */
-            if (elsize != sizeof(char *) && nodesize > s->space) return 0;
+             * space; a corrupt count would ask for petabytes, and one of 2^61 or more
+             * wraps count*elsize to a small block that the element loop then overruns
+             * (undefined behaviour in the reference).  Fail such packets up front: the
+             * element loop below would fail them anyway. */
+            if (elsize != sizeof(char *) && c > s->space / elsize) return 0;    /* (count*elsize may wrap) */
             if (elsize == sizeof(char *) && c > s->space) return 0;
             *addrp = calloc((size_t)nodesize, 1);
             target = (char *)*addrp;

@@ -11,6 +11,11 @@ pytestmark = pytest.mark.gpu
 
 from mrnet_amd import wave as W  # noqa: E402
 
+import os
+
+# MRPDR_SOAK=k multiplies the number of drawn cases (a longer run of the same tests, by hand)
+SOAK = max(1, int(os.environ.get("MRPDR_SOAK", "1")))
+
 SCALARS = ["c", "uc", "hd", "uhd", "d", "ud", "ld", "uld", "f", "lf"]
 VARS = ["s", "as", "As"] + ["a" + t for t in SCALARS] + ["A" + t for t in SCALARS]
 SEPS = [" ", "  ", "\t", " \n"]
@@ -44,7 +49,7 @@ def blank_like(cols):
                      blank(c.sub_offs), c.sub_capacity) for c in cols]
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(120 * SOAK))
 def test_random_format_round_trip(codec, seed):
     fmt_s, n, max_count, align, phase = draw(1000 + seed)
     if n * max_count > 400000:
@@ -81,7 +86,7 @@ def test_random_format_round_trip(codec, seed):
     assert codec.status() == 0
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SOAK))
 def test_random_truncation(codec, seed):
     """Every packet cut at a random length (a third of them left whole): per-packet ok flags and
     the columns of what did decode, against the oracle."""
@@ -120,7 +125,7 @@ def mixed_arena(fmt_s, arena, offs, lens, orders):
     return out
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(60 * SOAK))
 def test_random_mixed_byte_orders(codec, seed):
     """A wave collected from senders of both byte orders (src/Packet.C:96,118: every packet is
     decoded with the order its message announced), whole and truncated packets."""
@@ -163,7 +168,7 @@ def test_mixed_orders_large_arrays(codec):
     assert columns_equal(host_cols(fmt, dcols, n), ocols)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(40 * SOAK))
 def test_random_garbage(codec, seed):
     """Packets of random bytes (length prefixes of any size, zero string lengths, counts beyond the
     packet): the per-packet verdicts and whatever decoded before the first bad field must equal the
