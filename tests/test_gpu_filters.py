@@ -264,3 +264,52 @@ def test_fused_min_max_avg_equals_the_three_filters(codec, tok, t, dt):
             one, ok1 = codec.filter_raw(op, t, base, w + 4, base + w, w + 4, n, 0, W.SHAPE_TREE)
             assert int(oks[k].item()) == int(ok1.item()), (tok, n, op)
             assert torch.equal(res[16 * k:16 * k + 16], one), (tok, n, op)
+
+
+import os  # noqa: E402
+
+SOAK = max(1, int(os.environ.get("MRPDR_SOAK", "1")))
+
+
+@pytest.mark.parametrize("seed", range(80 * SOAK))
+def test_random_filters(codec, seed):
+    """Drawn wave size, element type, operator, shape, field offset / packet stride and sender byte
+    order: the fold straight on the wire bytes against the oracle, bit for bit.  MIN / MAX see raw
+    bit patterns (NaNs and infinities included: selection copies bits), SUM / AVG finite values."""
+    r = splitmix64(31000 + seed, 16)
+    n = [1, 2, 3, 4, 5, 255, 1023, 1025, 4097, 20000, 70001][int(r[0] % np.uint64(11))]
+    if int(r[1] % np.uint64(4)) == 0:
+        n = int(r[2] % np.uint64(70000)) + 1
+    tok, t, dt = TYPES[int(r[3] % np.uint64(len(TYPES)))]
+    dt = np.dtype(dt)
+    ops = [O.SUM, O.MIN, O.MAX, O.AVG] + ([O.OR, O.AND] if dt.kind != "f" else [])
+    op = ops[int(r[4] % np.uint64(len(ops)))]
+    shape = W.SHAPE_FLAT if (n <= 5000 and int(r[5] % np.uint64(2))) else W.SHAPE_TREE
+    swap = int(r[6] % np.uint64(2))
+    pad_front, pad_back = int(r[7] % np.uint64(9)), int(r[8] % np.uint64(7))
+    if op in (O.MIN, O.MAX) and dt.kind == "f":
+        vals = random_values(dt, n, 500 + seed, finite=False)
+    else:
+        vals = values_for(dt, n, 500 + seed, op)
+    cnt = None
+    if op == O.AVG:
+        cnt = (splitmix64(seed + 7, n) % np.uint64(6)).astype(np.int32)          # zeros allowed
+    w = dt.itemsize
+    stride = pad_front + w + (4 if op == O.AVG else 0) + pad_back
+    rows = (splitmix64(seed + 9, n * stride) & np.uint64(0xFF)).astype(np.uint8).reshape(n, stride)
+    vb = vals.view(np.uint8).reshape(n, w)
+    rows[:, pad_front:pad_front + w] = vb[:, ::-1] if swap else vb
+    if op == O.AVG:
+        cb = cnt.view(np.uint8).reshape(n, 4)
+        rows[:, pad_front + w:pad_front + w + 4] = cb[:, ::-1] if swap else cb
+    dev = codec.to_device(rows.reshape(-1))
+    base = dev.data_ptr() + pad_front
+    res, ok = codec.filter_raw(op, t, base, stride, (base + w) if op == O.AVG else None, stride, n, swap, shape)
+    torch.cuda.synchronize()
+    got = W.result_value(res, ok, dt, op if op in (O.SUM, O.MIN, O.MAX, O.AVG) else O.SUM)
+    ref = O.filter_flat(op, t, vals, cnt) if shape == W.SHAPE_FLAT else O.filter_tree(op, t, vals, cnt, W.TREE_FANINS)
+    assert (got is None) == (ref is None), (tok, op, n, shape)
+    if ref is not None:
+        assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (tok, op, n, shape, swap)
+        if op == O.AVG:
+            assert got[1] == ref[1]
