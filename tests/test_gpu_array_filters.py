@@ -157,3 +157,78 @@ def test_perfdata_concat(codec):
         assert cnt == want.size
         assert np.array_equal(W.Codec.to_numpy(c.values).view(dt)[:cnt].view(np.uint8), want.view(np.uint8))
     assert codec.status() == 0
+
+
+import os  # noqa: E402
+
+SOAK = max(1, int(os.environ.get("MRPDR_SOAK", "1")))
+
+
+@pytest.mark.parametrize("seed", range(40 * SOAK))
+def test_random_perfdata(codec, seed):
+    """Drawn wave size, element type, operator, array lengths (many empty), rank arrays of 0-3
+    entries with aggregate (negative) ranks, and one- or two-level shapes, against the oracle."""
+    r = splitmix64(41000 + seed, 16)
+    n = [1, 2, 3, 64, 255, 256, 257, 1000, 4000][int(r[0] % np.uint64(9))]
+    if int(r[1] % np.uint64(3)) == 0:
+        n = int(r[2] % np.uint64(6000)) + 1
+    t = [O.UINT64_T, O.INT64_T, O.DOUBLE_T][int(r[3] % np.uint64(3))]
+    op = [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG][int(r[4] % np.uint64(4))]
+    kmax = [1, 3, 8, 40, 300, 600][int(r[5] % np.uint64(6))]
+    group = [0, 0, 2, 7, 64, 256, 1000][int(r[6] % np.uint64(7))]
+    dt = np.dtype(O.elem_dtype(t))
+    lens = (splitmix64(seed + 1, n) % np.uint64(kmax + 1)).astype(np.uint64)
+    lens[(splitmix64(seed + 2, n) % np.uint64(4)) == 0] = 0                      # a quarter carry no data
+    if int(r[7] % np.uint64(2)):
+        lens[lens > 0] = kmax                                                   # equal lengths, as real streams have
+    if dt.kind == "f":
+        vals = ((splitmix64(seed + 3, int(lens.sum())) % np.uint64(2000001)).astype(np.float64) - 1e6) * 1e-3
+    else:
+        vals = random_values(dt, int(lens.sum()), seed + 3) >> 3
+    rcnt = (splitmix64(seed + 4, n) % np.uint64(4)).astype(np.uint64)
+    R = int(rcnt.sum())
+    rvals = (splitmix64(seed + 5, R) % np.uint64(11)).astype(np.int32) - 6      # -6 .. 4
+    ranks, data = (rcnt, rvals), (lens, vals)
+    if group and group < n:
+        ref = O.filter_perfdata_tree(op, t, ranks, data, [group, 0])
+    else:
+        group = 0
+        ref = O.filter_perfdata(op, t, ranks, data)
+    nel = (np.ones(n, np.uint64), lens.astype(np.int32))
+    wave = P.PacketWave(codec, 5, 100, PERF_FMT[t], [ranks, nel, data], n)
+    out = P.tfilter_PerfData(wave, op, group=group)
+    assert out is not None and out.n == 1
+    cols = out.unpack(PERF_FMT[t])
+    torch.cuda.synchronize()
+    got_len = int(W.Codec.to_numpy(cols[2].counts).view(np.uint64)[0])
+    got = W.Codec.to_numpy(cols[2].values).view(dt)[:got_len]
+    assert ref is not None
+    assert got_len == ref[1].size, (n, t, op, kmax, group)
+    assert int(W.Codec.to_numpy(cols[0].values).view(np.int32)[0]) == ref[0]
+    assert np.array_equal(got.view(np.uint64), ref[1].view(np.uint64)), (n, t, op, kmax, group)
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("seed", range(25 * SOAK))
+def test_random_int_eq_class(codec, seed):
+    r = splitmix64(43000 + seed, 8)
+    n = int(r[0] % np.uint64([5, 300, 9000][int(r[1] % np.uint64(3))])) + 1
+    kmax = int(r[2] % np.uint64(7))
+    vrange = [1, 3, 50, 100000, 1 << 32][int(r[3] % np.uint64(5))]
+    mmax = int(r[4] % np.uint64(6))
+    kc = (splitmix64(seed + 1, n) % np.uint64(kmax + 1)).astype(np.uint64)
+    K = int(kc.sum())
+    vals = (splitmix64(seed + 2, K) % np.uint64(vrange)).astype(np.uint32)
+    mc = (splitmix64(seed + 3, K) % np.uint64(mmax + 1)).astype(np.uint32)
+    ko = np.zeros(n + 1, np.int64); np.cumsum(kc, out=ko[1:])
+    ec = np.array([int(mc[ko[i]:ko[i + 1]].sum()) for i in range(n)], np.uint64)
+    mems = (splitmix64(seed + 4, int(ec.sum())) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    want = O.filter_int_eq_class((kc, vals), (kc, mc), (ec, mems))
+    wave = P.PacketWave(codec, 3, 100, "%aud %aud %aud", [(kc, vals), (kc, mc), (ec, mems)], n)
+    out = P.tfilter_IntEqClass(wave)
+    cols = out.unpack("%aud %aud %aud")
+    torch.cuda.synchronize()
+    for c, w in zip(cols, want):
+        cnt = int(W.Codec.to_numpy(c.counts).view(np.uint64)[0])
+        assert cnt == w.size and np.array_equal(W.Codec.to_numpy(c.values).view(np.uint32)[:cnt], w), (n, kmax, vrange, mmax)
+    assert codec.status() == 0
