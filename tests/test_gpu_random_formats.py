@@ -259,3 +259,45 @@ def test_decode_into_columns_too_small(codec, fmt_s, n, max_count, field):
     assert codec.status() & 1
     assert torch.equal(cols2[field].values, guard)
     assert codec.status() == 0                      # read and cleared
+
+
+@pytest.mark.parametrize("seed", range(30 * SOAK))
+def test_random_headers(codec, seed):
+    """Drawn format string, wave size, per-packet stream ids / tags / source ranks and a destination
+    list: the encoded headers against the oracle's byte for byte, then decoded again -- also after
+    rewriting every other header as a big-endian sender would have."""
+    fmt_s, n, _, _, _ = draw(11000 + seed)
+    n = max(n, 1)
+    r = splitmix64(12000 + seed, 8)
+    ndest = [0, 0, 1, 3, 17][int(r[0] % np.uint64(5))]
+    dest = (splitmix64(seed + 1, ndest) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    sids = (splitmix64(seed + 2, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    tags = (splitmix64(seed + 3, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.int32)
+    srcs = (splitmix64(seed + 4, n) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    fmt = W.Format(fmt_s)
+    hdrs, stride = codec.encode_headers(fmt, n, stream_ids=codec.to_device(sids), tags=codec.to_device(tags),
+                                        src_ranks=codec.to_device(srcs),
+                                        dest_ranks=codec.to_device(dest) if ndest else None)
+    torch.cuda.synchronize()
+    h = W.Codec.to_numpy(hdrs)[:n * stride].reshape(n, stride).copy()
+    for i in sorted(set([0, n // 2, n - 1] + [int(x % np.uint64(n)) for x in splitmix64(seed + 5, 6)])):
+        want = O.header_encode(int(sids[i]), int(tags[i]), int(srcs[i]), fmt_s, dest=dest.tolist())
+        assert want.size == stride and h[i].tobytes() == want.tobytes(), (fmt_s, i)
+    flen = len(fmt_s) + 1
+    for i in range(1, n, 2):                        # every other header from a big-endian sender
+        for a in (0, 4, 8, 12):
+            h[i, a:a + 4] = h[i, a:a + 4][::-1].copy()
+        e = 16 + flen
+        h[i, e:e + 8] = h[i, e:e + 8][::-1].copy()
+        for k in range(ndest):
+            h[i, e + 8 + 4 * k:e + 12 + 4 * k] = h[i, e + 8 + 4 * k:e + 12 + 4 * k][::-1].copy()
+        h[i, stride - 1] = 1
+    out = codec.decode_headers(fmt, n, codec.to_device(h.reshape(-1)), stride=stride, max_dest=max(ndest, 1))
+    assert bool(out["ok"].all())
+    assert np.array_equal(W.Codec.to_numpy(out["stream_id"]).view(np.uint32), sids)
+    assert np.array_equal(W.Codec.to_numpy(out["tag"]), tags)
+    assert np.array_equal(W.Codec.to_numpy(out["src_rank"]).view(np.uint32), srcs)
+    assert np.array_equal(W.Codec.to_numpy(out["byteorder"]), (np.arange(n) % 2).astype(np.uint8))
+    assert bool((out["ndest"] == ndest).all())
+    if ndest:
+        assert np.array_equal(W.Codec.to_numpy(out["dest_ranks"]).view(np.uint32), np.tile(dest, (n, 1)))
