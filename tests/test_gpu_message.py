@@ -86,3 +86,34 @@ def test_message_truncated_is_rejected(codec):
     with pytest.raises(W.PdrError):
         codec.message_parse(W.Format(fmt_s), codec.to_device(ref[:-3]))
     assert O.message_parse(ref[:-3]) is None
+
+
+import os  # noqa: E402
+
+from test_gpu_random_formats import draw  # noqa: E402
+
+SOAK = max(1, int(os.environ.get("MRPDR_SOAK", "1")))
+
+
+@pytest.mark.parametrize("seed", range(30 * SOAK))
+def test_random_messages(codec, seed):
+    """Drawn format string and wave size: the message built on the device equals the oracle's byte
+    for byte, and the oracle's message parses and decodes back to the columns."""
+    fmt_s, n, max_count, _, _ = draw(15000 + seed)
+    if n * max_count > 200000:
+        max_count = 40
+    ocols = make_wave(fmt_s, n, seed=seed + 3, max_count=max_count)
+    ranks = (np.arange(n, dtype=np.uint32) * 3 + seed).astype(np.uint32)
+    ref, arena, offs, lens = oracle_message(fmt_s, ocols, n, (1 << 30) + seed, 100 + seed, ranks)
+    fmt = W.Format(fmt_s)
+    msg = codec.message_build(fmt, dev_cols(codec, fmt, ocols), n, stream_id=(1 << 30) + seed, tag=100 + seed,
+                              src_ranks=codec.to_device(ranks) if n else None)
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(msg), ref), (fmt_s, n)
+    cnt, hdr, wire = codec.message_parse(fmt, codec.to_device(ref))
+    assert cnt == n and W.Codec.to_numpy(hdr["ok"]).tolist() == [1] * n
+    assert np.array_equal(W.Codec.to_numpy(hdr["src_rank"]).view(np.uint32), ranks)
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert W.Codec.to_numpy(ok).tolist() == [1] * n
+    assert columns_equal(host_cols(fmt, dcols, n), ocols), (fmt_s, n)
+    assert codec.status() == 0
