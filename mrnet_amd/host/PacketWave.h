@@ -14,6 +14,8 @@
 //   tfilter_Sum / Max / Min / Avg                   one output packet with the stream id and tag
 //                                                    of the first input (src/FilterDefinitions.C:151-221)
 //   tfilter_ArrayConcat / PerfData / IntEqClass     the array filters (src/FilterDefinitions.C:649-1239)
+//   PacketWave(ctx, fmt, msg, bytes) / to_message    Message::recv / Message::send for the wave
+//                                                    (src/Message.C:48-335)
 #pragma once
 
 #include <hip/hip_runtime_api.h>
@@ -344,6 +346,69 @@ class PacketWave {
         decode_pdr_header();
     }
 
+    // ---- receive-side constructor from one Message (src/Message.C:48-199) ------------------
+    // msg: the bytes of one message as they came off the link (byte order, packet count, size
+    // vector, spare byte, then header and data buffer of every packet).  The host reads the
+    // 5-byte count, as Message::recv does before it knows how much more to receive; size
+    // vector, headers and data are taken apart on the device, in place.
+    PacketWave(WaveContext &wc, const char *fmt, const uint8_t *msg, uint64_t msg_bytes)
+        : wc_(wc), fmt_(mrpdr_fmt_compile(fmt)), n_(0), stream_id_((uint32_t)-1), tag_(-1),
+          byteorder_(MRPDR_LITTLEENDIAN), decoded_(false), error_(false), have_hdrs_(true)
+    {
+        if (!fmt_) throw PdrError("mrpdr_fmt_compile");
+        if (msg_bytes < 5) throw std::runtime_error("PacketWave: message shorter than its count");
+        const bool be = msg[0] != MRPDR_LITTLEENDIAN;           // the count is in the sender's order (:78)
+        n_ = be ? ((uint32_t)msg[1] << 24 | (uint32_t)msg[2] << 16 | (uint32_t)msg[3] << 8 | msg[4])
+                : ((uint32_t)msg[4] << 24 | (uint32_t)msg[3] << 16 | (uint32_t)msg[2] << 8 | msg[1]);
+        const uint64_t pre = mrpdr_message_preamble_bytes(n_);
+        if (msg_bytes < pre) throw std::runtime_error("PacketWave: message shorter than its size vector");
+        d_msg_.upload(msg, msg_bytes, wc_.stream);
+        d_hoffs_.resize(8 * (n_ + 1)); d_hlens_.resize(8 * (n_ ? n_ : 1));
+        d_offs_.resize(8 * (n_ + 1));  d_lens_.resize(8 * (n_ ? n_ : 1));
+        uint64_t payload = 0;
+        if (!mrpdr_message_parse_sizes(wc_.ctx, d_msg_.ptr<uint8_t>() + 5, n_, d_hoffs_.ptr<uint64_t>(),
+                                       d_hlens_.ptr<uint64_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(),
+                                       &payload, wc_.stream)) throw PdrError("mrpdr_message_parse_sizes");
+        if (pre + payload > msg_bytes) throw std::runtime_error("PacketWave: message shorter than its size vector announces");
+        arena_bytes_ = payload;
+        in_message_ = true;
+        have_hdrs_ = false;             // the headers lie between the data buffers: get_Headers re-encodes them
+        msg_pre_ = pre;
+        decode_pdr_header();
+    }
+
+    // Message::send (src/Message.C:201-335) for this wave: the bytes one write() puts on the link,
+    // headers and data encoded at their final place in one device buffer, one copy to the host.
+    void to_message(std::vector<uint8_t> &out, const std::vector<uint32_t> *src_ranks = nullptr)
+    {
+        decode_pdr_data();                                       // a received wave is re-encoded from its columns
+        if (!src_ranks && src_ranks_.size() == n_ && n_) src_ranks = &src_ranks_;     // forwarded as received
+        const uint64_t h = mrpdr_header_bytes(fmt_);
+        const uint64_t pre = mrpdr_message_preamble_bytes(n_);
+        DeviceBuffer d_lens, d_offs, d_out, d_src;
+        d_lens.resize(8 * (n_ ? n_ : 1)); d_offs.resize(8 * (n_ + 1));
+        uint64_t payload = 0;
+        if (!mrpdr_wave_sizeof(wc_.ctx, fmt_, cols_.data(), n_, 1, (uint32_t)h, d_lens.ptr<uint64_t>(),
+                               d_offs.ptr<uint64_t>(), &payload, wc_.stream)) throw PdrError("mrpdr_wave_sizeof");
+        d_out.resize(pre + payload);
+        hip_check(hipMemsetAsync(d_out.ptr<void>(), 0, pre + payload, wc_.stream), "hipMemsetAsync");
+        uint8_t *m = d_out.ptr<uint8_t>();
+        if (!mrpdr_message_write_preamble(wc_.ctx, n_, h, d_lens.ptr<uint64_t>(), m, wc_.stream))
+            throw PdrError("mrpdr_message_write_preamble");
+        if (n_) {
+            mrpdr_wire w{ m + pre, d_offs.ptr<uint64_t>(), d_lens.ptr<uint64_t>(), 0, payload };
+            if (!mrpdr_wave_encode(wc_.ctx, fmt_, cols_.data(), n_, &w, wc_.stream)) throw PdrError("mrpdr_wave_encode");
+            const uint32_t *src = nullptr;
+            if (src_ranks) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
+            if (!mrpdr_wave_encode_headers(wc_.ctx, fmt_, n_, stream_id_, nullptr, tag_, nullptr, 0xFFFFFFFFu, src,
+                                           nullptr, 0, m + pre - h, d_offs.ptr<uint64_t>(), 0, wc_.stream))
+                throw PdrError("mrpdr_wave_encode_headers");
+        }
+        out.resize(pre + payload);
+        d_out.download(out.data(), pre + payload, wc_.stream);
+        wc_.sync();
+    }
+
     ~PacketWave() { mrpdr_fmt_free(fmt_); }
     PacketWave(const PacketWave &) = delete;
     PacketWave &operator=(const PacketWave &) = delete;
@@ -363,7 +428,9 @@ class PacketWave {
         arena.resize(arena_bytes_);
         offsets.resize(n_);
         lens.resize(n_);
-        d_arena_.download(arena.data(), arena_bytes_, wc_.stream);
+        if (arena_bytes_)
+            hip_check(hipMemcpyAsync(arena.data(), wire_.base, arena_bytes_, hipMemcpyDeviceToHost, wc_.stream),
+                      "hipMemcpyAsync D2H");
         d_offs_.download(offsets.data(), 8 * n_, wc_.stream);
         d_lens_.download(lens.data(), 8 * n_, wc_.stream);
         wc_.sync();
@@ -372,6 +439,7 @@ class PacketWave {
     // Encoded headers, get_HeaderLen() bytes each (lazy: Message::send asks for them).
     void get_Headers(std::vector<uint8_t> &hdrs, const std::vector<uint32_t> *src_ranks = nullptr)
     {
+        if (!src_ranks && src_ranks_.size() == n_ && n_) src_ranks = &src_ranks_;     // as received
         if (!have_hdrs_) encode_pdr_header(src_ranks);
         hdrs.resize((size_t)n_ * hdr_len_);
         d_hdrs_.download(hdrs.data(), hdrs.size(), wc_.stream);
@@ -502,7 +570,9 @@ class PacketWave {
     {
         DeviceBuffer d_sid, d_tag, d_src, d_bo, d_ok;
         d_sid.resize(4 * n_); d_tag.resize(4 * n_); d_src.resize(4 * n_); d_bo.resize(n_); d_ok.resize(4 * n_);
-        if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, d_hdrs_.ptr<uint8_t>(), nullptr, nullptr, hdr_len_,
+        const uint8_t *hdr_base = in_message_ ? d_msg_.ptr<uint8_t>() + msg_pre_ : d_hdrs_.ptr<uint8_t>();
+        if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, hdr_base, in_message_ ? d_hoffs_.ptr<uint64_t>() : nullptr,
+                                       in_message_ ? d_hlens_.ptr<uint64_t>() : nullptr, hdr_len_,
                                        d_sid.ptr<uint32_t>(), d_tag.ptr<int32_t>(), d_src.ptr<uint32_t>(),
                                        d_bo.ptr<uint8_t>(), nullptr, nullptr, 0, d_ok.ptr<int32_t>(), wc_.stream))
             throw PdrError("mrpdr_wave_decode_headers");
@@ -520,7 +590,8 @@ class PacketWave {
             if (bo[i] != bo[0]) mixed_ = true;                // children of both kinds: each packet keeps its order
         }
         if (mixed_) d_orders_.upload(bo.data(), n_, wc_.stream), wc_.sync();
-        wire_ = mrpdr_wire{ d_arena_.ptr<uint8_t>(), d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, arena_bytes_ };
+        uint8_t *arena = in_message_ ? d_msg_.ptr<uint8_t>() + msg_pre_ : d_arena_.ptr<uint8_t>();
+        wire_ = mrpdr_wire{ arena, d_offs_.ptr<uint64_t>(), d_lens_.ptr<uint64_t>(), 0, arena_bytes_ };
     }
 
     void decode_pdr_data()                       // src/Packet.C:106-133, lazy and idempotent
@@ -587,6 +658,9 @@ class PacketWave {
     unsigned hdr_len_ = 0;
     uint64_t arena_bytes_ = 0;
     DeviceBuffer d_hdrs_, d_arena_, d_offs_, d_lens_, d_orders_;
+    DeviceBuffer d_msg_, d_hoffs_, d_hlens_;   // a wave received as one Message: decoded in place
+    bool in_message_ = false;
+    uint64_t msg_pre_ = 0;
     std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_, d_subc_, d_subo_;
     std::vector<mrpdr_column> cols_;
     std::vector<uint64_t> totals_;

@@ -373,6 +373,56 @@ static void test_group_by_format(WaveContext &wc)
     end_SubTest("group_by_format", ok);
 }
 
+// Message::send / Message::recv for a wave (src/Message.C:48-335): layout of the message, and the
+// wave that comes back out of it.
+static void test_message(WaveContext &wc)
+{
+    const char *fmt = "%d %s %auhd";
+    const uint64_t nb = 9;
+    std::vector<HostColumn> cols(3);
+    std::vector<int32_t> v(nb);
+    std::vector<uint16_t> arr;
+    std::vector<uint64_t> cnt(nb);
+    for (uint64_t i = 0; i < nb; i++) { v[i] = (int32_t)i - 4; cnt[i] = i % 4; for (uint64_t k = 0; k < cnt[i]; k++) arr.push_back((uint16_t)(100 * i + k)); }
+    cols[0].set_scalars(v);
+    cols[1] = strings(nb, "Test String");
+    cols[2].set_arrays(cnt, arr);
+    PacketWave sent(wc, 77, 105, fmt, cols, nb);
+    std::vector<uint32_t> src(nb);
+    for (uint64_t i = 0; i < nb; i++) src[i] = (uint32_t)(1000 + i);
+    std::vector<uint8_t> msg;
+    sent.to_message(msg, &src);
+    // layout: byte order, count, 2n sizes, spare byte, then hdr0 buf0 hdr1 buf1 ...
+    std::vector<uint8_t> arena;
+    std::vector<uint64_t> offs, lens;
+    sent.get_Buffers(arena, offs, lens);
+    const uint64_t h = sent.get_HeaderLen();
+    bool ok = msg.size() > 5 && msg[0] == 0 && msg[1] == nb && msg[2] == 0 && msg[3] == 0 && msg[4] == 0;
+    uint64_t at = 5 + 16 * nb + 1;
+    for (uint64_t i = 0; ok && i < nb; i++) {
+        uint64_t hs, bs;
+        memcpy(&hs, &msg[5 + 16 * i], 8); memcpy(&bs, &msg[5 + 16 * i + 8], 8);
+        ok = hs == h && bs == lens[i] && !memcmp(&msg[at + h], &arena[offs[i]], lens[i]);
+        at += h + lens[i];
+    }
+    ok = ok && at == msg.size();
+    if (!ok) printf("  (message layout differs)\n");
+    PacketWave got(wc, fmt, msg.data(), msg.size());
+    std::vector<HostColumn> out;
+    ok = ok && !got.has_Error() && got.size() == nb && got.get_StreamId() == 77 && got.get_Tag() == 105 &&
+         got.get_SourceRanks() == src && got.unpack(fmt, out) == 0 && !got.has_Error();
+    ok = ok && out[0].values == cols[0].values && out[1].values == cols[1].values && out[2].values == cols[2].values &&
+         out[2].counts == cnt;
+    if (!ok) printf("  (received wave differs)\n");
+    std::vector<uint8_t> again;
+    got.to_message(again);                                      // forwarded: the same bytes go out again
+    ok = ok && again == msg;
+    std::vector<uint8_t> cut(msg.begin(), msg.end() - 2);
+    bool refused = false;
+    try { PacketWave bad(wc, fmt, cut.data(), cut.size()); } catch (const std::exception &) { refused = true; }
+    end_SubTest("Message::send / recv of a wave", ok && refused);
+}
+
 int main()
 {
     try {
@@ -398,6 +448,7 @@ int main()
         test_array_filters(wc);
         test_both_byte_orders(wc);
         test_group_by_format(wc);
+        test_message(wc);
     } catch (const std::exception &e) {
         printf("exception: %s\nMRNTEST_FAILURE\n", e.what());
         failures++;

@@ -18,4 +18,4 @@ def test_cpp_packet_wave_program():
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0
     assert "MRNTEST_FAILURE" not in r.stdout
-    assert r.stdout.count("MRNTEST_SUCCESS") >= 63
+    assert r.stdout.count("MRNTEST_SUCCESS") >= 64
