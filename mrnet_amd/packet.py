@@ -76,6 +76,34 @@ class PacketWave:
             self.stream_id, self.tag, self.byteorder = 0xFFFFFFFF, -1, W.LITTLEENDIAN
         return self
 
+    @classmethod
+    def from_message(cls, codec, fmt, msg, inlet_rank=W.UNKNOWN_RANK):
+        """Message::recv (src/Message.C:48-199): the wave inside one message (uint8 device tensor),
+        headers and data decoded in place."""
+        self = cls.__new__(cls)
+        self.codec = codec
+        self.fmt = fmt if isinstance(fmt, W.Format) else W.Format(fmt)
+        n, h, wire = codec.message_parse(self.fmt, msg)
+        self.n, self.wire, self.inlet_rank = n, wire, inlet_rank
+        self._hdrs, self._hdr_stride = None, 0          # they lie between the data buffers
+        self.columns, self.ok, self._decoded, self._error = None, None, False, False
+        self.header, self.src_ranks, self.src_rank = h, h["src_rank"], W.UNKNOWN_RANK
+        self.stream_id, self.tag, self.byteorder = 0xFFFFFFFF, -1, W.LITTLEENDIAN
+        if n:
+            self.stream_id = int(h["stream_id"][0].item()) & 0xFFFFFFFF
+            self.tag = int(h["tag"][0].item())
+            bo = h["byteorder"]
+            self.byteorder = int(bo[0].item()) if bool((bo == bo[0]).all()) else bo
+            self._error = not bool(h["ok"].all())
+        return self
+
+    def to_message(self):
+        """Message::send (src/Message.C:201-335): the bytes one write() puts on the link (uint8
+        device tensor); a received wave goes out with the source ranks it came with."""
+        cols = self.unpack(self.fmt.text)
+        return self.codec.message_build(self.fmt, cols, self.n, stream_id=self.stream_id, tag=self.tag,
+                                        src_rank=self.src_rank, src_ranks=self.src_ranks)
+
     # ---- accessors (include/mrnet/Packet.h:48-74) ----------------------------------
     def get_Tag(self):
         return self.tag

@@ -117,3 +117,19 @@ def test_random_messages(codec, seed):
     assert W.Codec.to_numpy(ok).tolist() == [1] * n
     assert columns_equal(host_cols(fmt, dcols, n), ocols), (fmt_s, n)
     assert codec.status() == 0
+
+
+def test_packet_wave_through_a_message(codec):
+    """PacketWave.from_message / to_message: a wave taken out of the oracle's message and sent on
+    leaves as the same bytes."""
+    from mrnet_amd.packet import PacketWave
+    fmt_s, n = "%d %s %auhd", 321
+    ocols = make_wave(fmt_s, n, seed=8, max_count=11)
+    ranks = (np.arange(n, dtype=np.uint32) + 9).astype(np.uint32)
+    ref, _, _, _ = oracle_message(fmt_s, ocols, n, (1 << 30) + 1, 117, ranks)
+    wave = PacketWave.from_message(codec, fmt_s, codec.to_device(ref))
+    assert wave.size() == n and not wave.has_Error() and wave.get_StreamId() == (1 << 30) + 1 and wave.get_Tag() == 117
+    assert columns_equal(host_cols(wave.fmt, wave.unpack(fmt_s), n), ocols)
+    out = wave.to_message()
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(out), ref)
