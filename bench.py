@@ -687,9 +687,27 @@ def main():
         t5 = (time.perf_counter() - t5) / 20
         cnt5 = int(res5[8:12].view(torch.int32).item())
         assert int(ok5.item()) == 1 and cnt5 == n5 * world, "sharded Avg lost packets"
+        # the same for the performance-data shape: 131,072 x '%ad %ad %alf'[8] per rank, Avg, per-rank
+        # output packets gathered (80 bytes each) and folded once more
+        k5 = 8
+        fmtp = W.Format("%ad %ad %alf")
+        onesp = np.ones(n5, np.uint64)
+        colsp = codec.columns_from_numpy(fmtp, [
+            (onesp, (np.arange(n5, dtype=np.int32) + rank * n5)), (onesp, np.full(n5, k5, np.int32)),
+            (np.full(n5, k5, np.uint64), np.random.default_rng(50 + rank).normal(1e-3, 1e-4, n5 * k5))])
+        for _ in range(3):
+            pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
+        barrier()
+        t5b = time.perf_counter()
+        for _ in range(20):
+            pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
+        barrier()
+        t5b = (time.perf_counter() - t5b) / 20
+        assert int(pl5.item()) == k5 and int(pr5.item()) == -n5 * world, "sharded PerfData lost ranks"
         if rank == 0:
             out["extra"] = {"c5_sharded_avg_us_per_wave": round(t5 * 1e6, 1), "c5_packets": n5 * world,
-                            "c5_avg": float(res5[:8].view(torch.float64).item())}
+                            "c5_avg": float(res5[:8].view(torch.float64).item()),
+                            "c5b_sharded_perfdata_avg_us_per_wave": round(t5b * 1e6, 1)}
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)

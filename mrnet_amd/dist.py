@@ -96,11 +96,13 @@ def unpack_perfdata(rows, cap):
     return rank_col, data_col
 
 
-def perfdata_sharded(codec, op, dtype, ranks, data, n, cap, group=None):
+def perfdata_sharded(codec, op, dtype, ranks, data, n, cap, group=None, fanin=0):
     """tfilter_PerfData over a wave spread over the ranks of `group`; ranks / data are this rank's
-    decoded columns (n packets), cap bounds the result length.  Every rank returns the same
-    (out_data, out_len, out_rank)."""
-    out, out_len, out_rank = codec.filter_perfdata(op, dtype, ranks, data, n, out_cap=cap)
+    decoded columns (n packets), cap bounds the result length.  fanin > 0 folds the rank's own
+    packets as a two-level tree (nodes of `fanin` packets, then one node over them) before the
+    exchange -- a flat fold of a large shard is one long serial chain per element.  Every rank
+    returns the same (out_data, out_len, out_rank)."""
+    out, out_len, out_rank = codec.filter_perfdata(op, dtype, ranks, data, n, group=fanin, out_cap=cap)
     rows = gather_rows(pack_perfdata(out, out_len, out_rank, cap), group)
     rank_col, data_col = unpack_perfdata(rows, cap)
     return codec.filter_perfdata(op, dtype, rank_col, data_col, rows.shape[0], out_cap=cap)
