@@ -377,7 +377,9 @@ int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *ctx, const mrpdr_column *in, u
  *   group = 0 or >= n : one filter invocation over the n packets (a node with n children);
  *   0 < group < n     : a two-level tree -- nodes of `group` consecutive packets, then one node
  *                       over their outputs (the filter runs at every level, as in an MRNet
- *                       tree: AVG divides and re-weights per level).  Needs `scratch` of
+ *                       tree: AVG divides and re-weights per level; integer SUM / MIN / MAX
+ *                       give the bits of the one-node fold for any group, only faster: a
+ *                       node folds its packets one after the other).  Needs `scratch` of
  *                       mrpdr_perfdata_scratch_bytes(n, group, out_cap) bytes, 16-byte aligned. */
 uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap);
 int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,

@@ -232,3 +232,20 @@ def test_random_int_eq_class(codec, seed):
         cnt = int(W.Codec.to_numpy(c.counts).view(np.uint64)[0])
         assert cnt == w.size and np.array_equal(W.Codec.to_numpy(c.values).view(np.uint32)[:cnt], w), (n, kmax, vrange, mmax)
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX])
+def test_perfdata_integer_folds_do_not_depend_on_the_tree(codec, t, op):
+    """One node over 20,000 packets (computed as a two-level tree on the device) against the
+    oracle's single flat invocation: identical bits for integer SUM / MIN / MAX."""
+    n = 20000
+    ranks, data = perf_wave(n, t, seed=op + 3 * t, kmax=9, aggregated=True)
+    ref = O.filter_perfdata(op, t, ranks, data)
+    nel = (np.ones(n, np.uint64), data[0].astype(np.int32))
+    wave = P.PacketWave(codec, 5, 100, PERF_FMT[t], [ranks, nel, data], n)
+    cols = P.tfilter_PerfData(wave, op).unpack(PERF_FMT[t])
+    torch.cuda.synchronize()
+    got_len = int(W.Codec.to_numpy(cols[2].counts).view(np.uint64)[0])
+    assert got_len == ref[1].size and int(W.Codec.to_numpy(cols[0].values).view(np.int32)[0]) == ref[0]
+    assert np.array_equal(W.Codec.to_numpy(cols[2].values).view(np.uint64)[:got_len], ref[1].view(np.uint64))
