@@ -72,8 +72,10 @@ enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 
 /*
  * Shape of the reduction a filter call applies to a wave.
  *   MRPDR_SHAPE_FLAT  one left fold over all n packets, i.e. exactly one call of the
- *                     reference's tfilter_* on the whole wave (serial; exact for every
- *                     type and operator at any n)
+ *                     reference's tfilter_* on the whole wave (exact for every type and
+ *                     operator at any n; serial where the order matters -- float types,
+ *                     every AVG -- while integer SUM / MIN / MAX / OR / AND, whose bits do
+ *                     not depend on the order, are computed level by level)
  *   MRPDR_SHAPE_TREE  the same fold applied level by level over a fixed tree, the way
  *                     an MRNet tree applies it at every internal node:
  *                     fan-in 4, then 2,2,2,2,2,2, then 4, then all remaining nodes

@@ -1018,6 +1018,10 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
     uint8_t *res = (uint8_t *)result;
     hipStream_t st = (hipStream_t)stream;
+    // Integer Sum (wrap-around), Min, Max, OR and AND do not depend on the order of the fold: the
+    // one-call (flat) result is computed level by level, same bits, no serial chain over n packets.
+    if (shape == MRPDR_SHAPE_FLAT && op != MRPDR_AVG && type != MRPDR_FLOAT_T && type != MRPDR_DOUBLE_T)
+        shape = MRPDR_SHAPE_TREE;
     switch (type) {
     case MRPDR_CHAR_T:   return run_filter_op<int8_t>(c, op, shape, in, res, result_ok, st);
     case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(c, op, shape, in, res, result_ok, st);
