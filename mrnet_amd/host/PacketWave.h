@@ -813,6 +813,9 @@ inline int tfilter_PerfData(PacketWave &in, int aggr_id, std::vector<HostColumn>
         return 0;
     }
     if (aggr_id != MRPDR_SUM && aggr_id != MRPDR_MIN && aggr_id != MRPDR_MAX && aggr_id != MRPDR_AVG) return -1;
+    // integer SUM / MIN / MAX do not depend on the fold order: a large node is computed as a
+    // two-level tree, same bits, without a serial chain over all n packets
+    if (group == 0 && n > 2048 && aggr_id != MRPDR_AVG && type != MRPDR_DOUBLE_T) group = 256;
     std::vector<uint64_t> lens(n);
     hip_check(hipMemcpyAsync(lens.data(), cols[2].counts, 8 * n, hipMemcpyDeviceToHost, wc.stream), "hipMemcpyAsync D2H");
     wc.sync();
