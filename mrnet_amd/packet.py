@@ -247,6 +247,13 @@ def tfilter_Avg(ipackets, shape=W.SHAPE_TREE):
     return _run_filter(W.TFILTER_AVG, ipackets, shape)
 
 
+def tfilter_IntSum(ipackets, shape=W.SHAPE_TREE):
+    """src/FilterDefinitions.C:71-88 (defined there, not registered): the int sum of '%d' packets."""
+    if ipackets.fmt.text != "%d":
+        return None
+    return _run_filter(W.TFILTER_SUM, ipackets, shape)
+
+
 def _from_columns(ipackets, fmt, columns):
     """One output packet with the stream id and tag of the first input, built from device columns."""
     return PacketWave(ipackets.codec, ipackets.get_StreamId(), ipackets.get_Tag(), fmt, columns, n=1)
