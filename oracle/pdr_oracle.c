@@ -172,6 +172,9 @@ int32_t orc_bytes(orc_stream *s, char **cpp, uint64_t *sizep, uint64_t maxsize) 
     switch (s->op) {
     case ORC_DECODE:
         if (n == 0) return 1;                     /* *cpp stays untouched (NULL) */
+        /* the reference mallocs the count it read before pdr_opaque finds the stream too short;
+         * a corrupt count asks for exabytes.  Same verdict without the allocation: */
+        if (n > s->space) return 0;
         if (sp == NULL) *cpp = sp = (char *)malloc((size_t)n);
         if (sp == NULL) return 0;
         /* fall through */
@@ -206,6 +209,7 @@ int32_t orc_string(orc_stream *s, char **cpp, uint32_t maxsize)    /* src/pdr.c:
     case ORC_FREE: return 1;
     case ORC_DECODE:
         if (n32 == 0) return 0;   /* the reference writes sp[-1] here (undefined); refuse instead */
+        if (n32 > s->space) return 0;   /* pdr_opaque would refuse it after a malloc of up to 4 GiB */
         if (sp == NULL) { sp = (char *)malloc((size_t)n32); *cpp = sp; }
         if (sp == NULL) return 0;
         sp[n32 - 1] = '\0';
