@@ -337,6 +337,16 @@ int32_t mrpdr_wave_filter(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shap
                           uint64_t n, int32_t swap,
                           void *result, int32_t *result_ok, void *stream);
 
+/* The same over a wave whose packets come from senders of both byte orders: byteorders (device,
+ * n bytes, as mrpdr_wave_decode_headers writes them) says for every packet whether its value
+ * (and count) is byte-reversed, as (*pkt)[0] decodes every packet with the order of its own
+ * message (src/Packet.C:118). */
+int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shape,
+                                const void *values, uint64_t value_stride,
+                                const void *counts, uint64_t count_stride,
+                                uint64_t n, const uint8_t *byteorders,
+                                void *result, int32_t *result_ok, void *stream);
+
 /* tfilter_Min, tfilter_Max and tfilter_Avg of one '<T> %d' wave in ONE pass over the packets
  * (a monitoring stream usually carries all three).  Same arguments as mrpdr_wave_filter with the
  * declared tree shape; results = 3 x 16 bytes (MIN, MAX, AVG output packets' data), results_ok = 3

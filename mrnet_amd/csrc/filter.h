@@ -125,15 +125,21 @@ struct FilterIn {
     const uint8_t *counts;  uint64_t count_stride;
     uint64_t n;
     int32_t  swap;
+    const uint8_t *orders;      // optional: sender byte order of every packet (then swap is unused)
 };
+
+__device__ inline bool filter_swap(const FilterIn &in, uint64_t i)
+{
+    return in.orders ? in.orders[i] != 0 : in.swap != 0;
+}
 
 template <typename T> __device__ inline T load_value(const FilterIn &in, uint64_t i)
 {
-    return from_bits<T>(ld_wire<sizeof(T)>(in.values + i * in.value_stride, in.swap != 0));
+    return from_bits<T>(ld_wire<sizeof(T)>(in.values + i * in.value_stride, filter_swap(in, i)));
 }
 __device__ inline int32_t load_count(const FilterIn &in, uint64_t i)
 {
-    return (int32_t)(uint32_t)ld_wire<4>(in.counts + i * in.count_stride, in.swap != 0);
+    return (int32_t)(uint32_t)ld_wire<4>(in.counts + i * in.count_stride, filter_swap(in, i));
 }
 
 // The data bytes of the filter's output packet: T value [, int32 count], no padding

@@ -721,7 +721,7 @@ static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, c
     if (f->dev.nf == 0) return 1;
     if (f->nstrarr) HIP_OK(hipMemsetAsync(c->sa_bytes, 0, MRPDR_MAXF * sizeof(uint64_t), st));
     if (n) {
-        if (!orders && rows_path_ok(f, wd)) {
+        if (rows_path_ok(f, wd)) {
             const size_t lds = ROWS_PER_BLOCK * wd.stride;
             if (swap) k_rows_decode<true><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
             else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
@@ -1001,11 +1001,11 @@ static int32_t run_filter_op(mrpdr_ctx *c, int32_t op, int32_t shape, const Filt
     return fail("mrpdr_wave_filter: unknown operator %d", op);
 }
 
-extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
-                                     const void *values, uint64_t value_stride,
-                                     const void *counts, uint64_t count_stride,
-                                     uint64_t n, int32_t swap,
-                                     void *result, int32_t *result_ok, void *stream)
+static int32_t wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
+                           const void *values, uint64_t value_stride,
+                           const void *counts, uint64_t count_stride,
+                           uint64_t n, int32_t swap, const uint8_t *orders,
+                           void *result, int32_t *result_ok, void *stream)
 {
     if (!ctx_ready("mrpdr_wave_filter", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_filter: n exceeds the ctx limit");
@@ -1015,7 +1015,7 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
     if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
         return fail("mrpdr_wave_filter: bitwise operators need an integer type");
-    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
+    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap, orders };
     uint8_t *res = (uint8_t *)result;
     hipStream_t st = (hipStream_t)stream;
     // Integer Sum (wrap-around), Min, Max, OR and AND do not depend on the order of the fold: the
@@ -1036,6 +1036,27 @@ extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int
     }
     // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
     return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
+}
+
+extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
+                                     const void *values, uint64_t value_stride,
+                                     const void *counts, uint64_t count_stride,
+                                     uint64_t n, int32_t swap,
+                                     void *result, int32_t *result_ok, void *stream)
+{
+    return wave_filter(c, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
+                       result, result_ok, stream);
+}
+
+extern "C" int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
+                                           const void *values, uint64_t value_stride,
+                                           const void *counts, uint64_t count_stride,
+                                           uint64_t n, const uint8_t *byteorders,
+                                           void *result, int32_t *result_ok, void *stream)
+{
+    if (n && !byteorders) return fail("mrpdr_wave_filter_mixed: NULL byteorders");
+    return wave_filter(c, op, type, shape, values, value_stride, counts, count_stride, n, 0, n ? byteorders : nullptr,
+                       result, result_ok, stream);
 }
 
 template <typename T>
@@ -1059,7 +1080,7 @@ extern "C" int32_t mrpdr_wave_filter_stats(mrpdr_ctx *c, int32_t type, const voi
     if (n > c->max_packets) return fail("mrpdr_wave_filter_stats: n exceeds the ctx limit");
     if (!results || !results_ok) return fail("mrpdr_wave_filter_stats: NULL result");
     if (n && (!values || !counts)) return fail("mrpdr_wave_filter_stats: NULL values or counts");
-    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap };
+    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap, nullptr };
     uint8_t *res = (uint8_t *)results;
     hipStream_t st = (hipStream_t)stream;
     switch (type) {

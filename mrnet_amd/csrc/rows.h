@@ -44,6 +44,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode(FmtDev fmt, WireDev w
     const uint64_t i = p0 + threadIdx.x;
     const uint8_t *row = tile + threadIdx.x * stride;
     const uint64_t len = wire.lens ? wire.lens[i] : (uint64_t)fmt.fixed_bytes;
+    const bool sw = pkt_swap(wire, i, SWAP);        // the wave's order, or this packet's own
     bool good = true;
     for (int f = 0; f < fmt.nf; f++) {
         const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
@@ -53,13 +54,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode(FmtDev fmt, WireDev w
             if (((at | stride) & (w - 1)) == 0) {                 // naturally aligned in the LDS tile
                 switch (w) {
                 case 1: v = row[at]; break;
-                case 2: v = *reinterpret_cast<const uint16_t *>(row + at); if (SWAP) v = __builtin_bswap16((uint16_t)v); break;
-                case 4: v = *reinterpret_cast<const uint32_t *>(row + at); if (SWAP) v = __builtin_bswap32((uint32_t)v); break;
-                default: v = *reinterpret_cast<const uint64_t *>(row + at); if (SWAP) v = __builtin_bswap64(v); break;
+                case 2: v = *reinterpret_cast<const uint16_t *>(row + at); if (sw) v = __builtin_bswap16((uint16_t)v); break;
+                case 4: v = *reinterpret_cast<const uint32_t *>(row + at); if (sw) v = __builtin_bswap32((uint32_t)v); break;
+                default: v = *reinterpret_cast<const uint64_t *>(row + at); if (sw) v = __builtin_bswap64(v); break;
                 }
             } else {
                 for (uint32_t b = 0; b < w; b++) {
-                    const uint32_t src = SWAP ? (w - 1 - b) : b;  // src/byte_order.c:12-16
+                    const uint32_t src = sw ? (w - 1 - b) : b;    // src/byte_order.c:12-16
                     v |= (uint64_t)row[at + src] << (8 * b);
                 }
             }

@@ -211,7 +211,7 @@ def _run_filter(op, ipackets, shape):
     elif fmt.text not in _SCALAR_FORMATS:
         return None             # the reference logs "invalid packet type" and emits nothing
     wire = ipackets.wire
-    if wire.offsets is None and not isinstance(ipackets.byteorder, torch.Tensor):
+    if wire.offsets is None:
         res, ok = codec.filter_wire(op, fmt, wire, ipackets.byteorder, shape)      # fused decode
     else:
         cols = ipackets.unpack(fmt.text)

@@ -477,9 +477,14 @@ class Codec:
             result = self.empty(16, torch.uint8)
         if result_ok is None:
             result_ok = self.empty(1, torch.int32)
-        r = self._lib.mrpdr_wave_filter(self.handle, op, int(dtype), shape, values_ptr, value_stride,
-                                        counts_ptr, count_stride, n, swap, _ptr(result),
-                                        _ptr(result_ok), _stream())
+        if isinstance(swap, torch.Tensor):        # one sender byte order per packet (uint8 device tensor)
+            r = self._lib.mrpdr_wave_filter_mixed(self.handle, op, int(dtype), shape, values_ptr, value_stride,
+                                                  counts_ptr, count_stride, n, _ptr(swap), _ptr(result),
+                                                  _ptr(result_ok), _stream())
+        else:
+            r = self._lib.mrpdr_wave_filter(self.handle, op, int(dtype), shape, values_ptr, value_stride,
+                                            counts_ptr, count_stride, n, swap, _ptr(result),
+                                            _ptr(result_ok), _stream())
         _check(r, "mrpdr_wave_filter")
         return result, result_ok
 
@@ -562,8 +567,8 @@ class Codec:
             raise PdrError("filter_wire needs the packed layout")
         base = wire.arena.data_ptr()
         w = fmt.widths[0]
-        return self.filter_raw(op, fmt.types[0], base, wire.stride, base + w, wire.stride, wire.n,
-                               int(sender_bo != LITTLEENDIAN), shape)
+        swap = sender_bo if isinstance(sender_bo, torch.Tensor) else int(sender_bo != LITTLEENDIAN)
+        return self.filter_raw(op, fmt.types[0], base, wire.stride, base + w, wire.stride, wire.n, swap, shape)
 
 
 def result_value(result, result_ok, fmt_or_dtype, op):

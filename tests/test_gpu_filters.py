@@ -313,3 +313,34 @@ def test_random_filters(codec, seed):
         assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (tok, op, n, shape, swap)
         if op == O.AVG:
             assert got[1] == ref[1]
+
+
+@pytest.mark.parametrize("seed", range(30 * SOAK))
+def test_random_filters_mixed_byte_orders(codec, seed):
+    """The fold on the wire bytes of a wave whose packets come from senders of both byte orders
+    (every packet read with its own, src/Packet.C:118)."""
+    r = splitmix64(33000 + seed, 8)
+    n = int(r[0] % np.uint64([9, 3000, 70000][int(r[1] % np.uint64(3))])) + 1
+    tok, t, dt = TYPES[int(r[2] % np.uint64(len(TYPES)))]
+    dt = np.dtype(dt)
+    op = [O.SUM, O.MIN, O.MAX, O.AVG][int(r[3] % np.uint64(4))]
+    vals = values_for(dt, n, 700 + seed, op)
+    cnt = counts_for(n, seed) if op == O.AVG else None
+    orders = (splitmix64(seed + 5, n) % np.uint64(2)).astype(np.uint8)
+    w = dt.itemsize
+    stride = w + (4 if op == O.AVG else 0)
+    rows = np.zeros((n, stride), np.uint8)
+    vb = vals.view(np.uint8).reshape(n, w)
+    rows[:, :w] = np.where(orders[:, None] != 0, vb[:, ::-1], vb)
+    if op == O.AVG:
+        cb = cnt.view(np.uint8).reshape(n, 4)
+        rows[:, w:] = np.where(orders[:, None] != 0, cb[:, ::-1], cb)
+    dev = codec.to_device(rows.reshape(-1))
+    res, ok = codec.filter_raw(op, t, dev.data_ptr(), stride, (dev.data_ptr() + w) if op == O.AVG else None, stride, n,
+                               codec.to_device(orders), W.SHAPE_TREE)
+    torch.cuda.synchronize()
+    got = W.result_value(res, ok, dt, op)
+    ref = O.filter_tree(op, t, vals, cnt, W.TREE_FANINS)
+    assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (tok, op, n)
+    if op == O.AVG:
+        assert got[1] == ref[1]

@@ -301,3 +301,17 @@ def test_random_headers(codec, seed):
     assert bool((out["ndest"] == ndest).all())
     if ndest:
         assert np.array_equal(W.Codec.to_numpy(out["dest_ranks"]).view(np.uint32), np.tile(dest, (n, 1)))
+
+
+@pytest.mark.parametrize("fmt_s", ["%d", "%lf %d", "%c %uhd %f %uld", "%hd %hd %hd"])
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 5000])
+def test_packed_scalar_wave_of_both_byte_orders(codec, fmt_s, n):
+    """Scalar-only packets side by side (the layout the LDS-staged row kernels take), every packet
+    in its own sender's byte order."""
+    ocols = make_wave(fmt_s, n, n + len(fmt_s))
+    arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+    orders = (splitmix64(n, n) % np.uint64(2)).astype(np.uint8)
+    src = mixed_arena(fmt_s, arena, offs, lens, orders)
+    fmt = W.Format(fmt_s)
+    dcols, ok = codec.decode(fmt, wire_from_numpy(codec, n, src, None, None, stride=fmt.fixed_bytes), codec.to_device(orders))
+    assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
