@@ -19,3 +19,13 @@ def test_cpp_packet_wave_program():
     assert r.returncode == 0
     assert "MRNTEST_FAILURE" not in r.stdout
     assert r.stdout.count("MRNTEST_SUCCESS") >= 64
+
+
+def test_c_abi_program():
+    """tests/host/test_c_abi.c: the C ABI used from plain C99 (gcc)."""
+    exe = os.path.join(ROOT, "tests", "host", "test_c_abi")
+    assert os.path.exists(exe), "build it with `make` (it travels with the tree, prebuilt)"
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "MRNTEST_FAILURE" not in r.stdout
+    assert r.stdout.count("MRNTEST_SUCCESS") == 5
