@@ -627,7 +627,8 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
         if (!(phases & 2)) return 1;
         bool timed;
         if (!perf_begin(c, st, &timed, 1)) return 0;
-        k_tile_encode<<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+        if (f->tv.nv <= TILE_SMALLV) k_tile_encode<TILE_SMALLV><<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+        else                         k_tile_encode<TILE_MAXV><<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
         LAUNCHED("k_tile_encode");
         return perf_end(c, st, timed, 1);
     }
@@ -728,8 +729,11 @@ static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, c
             LAUNCHED("k_rows_decode");
         } else if (!orders && tile_path_ok(f, wd, n)) {
             const uint32_t tiles = blocks_for(n, TILE_PKTS);
-            if (swap) k_tile_walk<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-            else      k_tile_walk<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+            const bool small = f->tv.nv <= TILE_SMALLV;
+            if (swap) { if (small) k_tile_walk<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+                        else       k_tile_walk<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
+            else      { if (small) k_tile_walk<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+                        else       k_tile_walk<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
             LAUNCHED("k_tile_walk");
             k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt, c->ntile_cnt);
             LAUNCHED("k_tile_offs");
@@ -781,8 +785,11 @@ static int32_t decode_finish(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
         bool timed;
         if (!perf_begin(c, st, &timed, 0)) return 0;
         const uint32_t tiles = blocks_for(n, TILE_PKTS);
-        if (swap) k_tile_decode<true><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
-        else      k_tile_decode<false><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+        const bool small = f->tv.nv <= TILE_SMALLV;
+        if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+                    else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
+        else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+                    else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
         LAUNCHED("k_tile_decode");
         return perf_end(c, st, timed, 0);
     }

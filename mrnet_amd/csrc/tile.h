@@ -36,13 +36,17 @@ struct TileVars {                       // the variable fields of the format, in
     int32_t field[TILE_MAXV];
 };
 
-struct TileLds {
+// MAXV = variable fields the tables hold: formats with up to 4 take the small form, which leaves
+// room for a fifth workgroup per CU (measured on a 1M-packet wave: +11 % throughput).
+template <int MAXV>
+struct TileLdsT {
     uint64_t start[TILE_PKTS + 1];      // arena offset of every packet of the tile
     uint64_t end[TILE_PKTS];
-    uint64_t seg[TILE_MAXV][TILE_PKTS + 1];   // offs[] of every variable field, in elements
-    uint64_t vpos[TILE_MAXV][TILE_PKTS];      // position of the field's length prefix in its packet
+    uint64_t seg[MAXV][TILE_PKTS + 1];  // offs[] of every variable field, in elements
+    uint64_t vpos[MAXV][TILE_PKTS];     // position of the field's length prefix in its packet
     int32_t  staged;
 };
+#define TILE_SMALLV 4
 
 // Address of arena byte x: in the LDS image (the image keeps the global address modulo 16, so
 // aligned 128-bit pieces of global memory are aligned pieces of the image) or in the arena.
@@ -65,8 +69,8 @@ __device__ __forceinline__ void st16_u(uint8_t *p, u32x4 v)
 
 // Packet boundaries (and, with SEGS, the offs[] of the variable fields) of the tile into LDS
 // in one round of global loads; decides whether the tile can be staged.
-template <bool SEGS>
-__device__ __forceinline__ void tile_load_meta(TileLds &m, const TileVars &tv, const WireDev &wire,
+template <bool SEGS, typename L>
+__device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const WireDev &wire,
                                                const ColsDev &cols, uint64_t p0, uint32_t np)
 {
     const uint32_t t = threadIdx.x;
@@ -91,7 +95,8 @@ __device__ __forceinline__ void tile_load_meta(TileLds &m, const TileVars &tv, c
 }
 
 // Bytes of the variable fields in front of field f in packet i of the tile.
-__device__ __forceinline__ uint64_t tile_var_before(const TileLds &m, const TileVars &tv, const FmtDev &fmt,
+template <typename L>
+__device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &tv, const FmtDev &fmt,
                                                     int f, uint32_t i)
 {
     uint64_t b = 0;
@@ -144,8 +149,8 @@ __device__ __forceinline__ void tile_copy_run(uint8_t *w, uint8_t *d, uint64_t l
 // packets (two 128-bit pieces each, then one tail element each) all issued before the first LDS
 // store.  A lane waits for memory twice per field instead of once per piece: the loads are
 // what the staged encode spends its time on, the stores go to LDS.
-template <int W>
-__device__ __forceinline__ void tile_fill_field(TileLds &m, uint8_t *img, int v, uint32_t pre, const uint8_t *dense,
+template <int W, typename L>
+__device__ __forceinline__ void tile_fill_field(L &m, uint8_t *img, int v, uint32_t pre, const uint8_t *dense,
                                                 uint32_t np, uint64_t lo, uint32_t mis)
 {
     typedef typename UIntOf<W>::type U;
@@ -198,8 +203,8 @@ __device__ __forceinline__ void tile_fill_field(TileLds &m, uint8_t *img, int v,
         for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u) st16_u(w[k] + o, ld16_any<false>(d[k] + o));
 }
 
-template <bool STAGED, bool ENCODE, bool SWAP, int W>
-__device__ __forceinline__ void tile_copy_field(TileLds &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
+template <bool STAGED, bool ENCODE, bool SWAP, int W, typename L>
+__device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
                                                 uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
 {
     if (STAGED && ENCODE) {
@@ -222,8 +227,8 @@ __device__ __forceinline__ void tile_copy_field(TileLds &m, uint8_t *img, const 
     }
 }
 
-template <bool STAGED, bool ENCODE, bool SWAP>
-__device__ __forceinline__ void tile_copy_fields(TileLds &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
+template <bool STAGED, bool ENCODE, bool SWAP, typename L>
+__device__ __forceinline__ void tile_copy_fields(L &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
                                                  const WireDev &wire, const ColsDev &cols, uint32_t np)
 {
     const uint64_t lo = m.start[0];
@@ -245,8 +250,8 @@ __device__ __forceinline__ void tile_copy_fields(TileLds &m, uint8_t *img, const
 // ---------------------------------------------------------------------------
 // encode
 // ---------------------------------------------------------------------------
-template <bool STAGED>
-__device__ __forceinline__ void tile_encode_body(TileLds &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
+template <bool STAGED, typename L>
+__device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDev &fmt, const TileVars &tv,
                                                  const WireDev &wire, const ColsDev &cols, uint64_t p0, uint32_t np)
 {
     const uint32_t t = threadIdx.x;
@@ -314,9 +319,10 @@ __device__ __forceinline__ void tile_encode_body(TileLds &m, uint8_t *img, const
     }
 }
 
+template <int V>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols, uint64_t n)
 {
-    __shared__ TileLds m;
+    __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
@@ -328,12 +334,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars 
 // ---------------------------------------------------------------------------
 // decode, begin: walk
 // ---------------------------------------------------------------------------
-template <bool SWAP>
+template <bool SWAP, int V>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                          uint64_t n, int32_t *ok, uint64_t *tile_sums,
                                                          uint64_t ntiles)
 {
-    __shared__ TileLds m;
+    __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
@@ -411,11 +417,11 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev co
 // ---------------------------------------------------------------------------
 // decode, finish: payloads
 // ---------------------------------------------------------------------------
-template <bool SWAP>
+template <bool SWAP, int V>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                            uint64_t n, uint32_t *status)
 {
-    __shared__ TileLds m;
+    __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
     __shared__ int32_t too_small;
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
