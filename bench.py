@@ -337,7 +337,7 @@ def perfdata_extra(codec):
     return {"c5b_perfdata_avg_us_per_wave": round(t * 1e6, 1)}
 
 
-def mixed_wave_extra(codec, n=65536, key="c4"):
+def mixed_wave_extra(codec, n=65536, key="c4", align=16):
     """Config 4: 65,536 packets '%d %uld %lf %s %auc' with variable-length fields (string length
     geometric, mean 12, max 255; byte array length uniform in [0, 512]).  With n = 1,048,576 (key
     c4_x16) the same wave sixteen times over: what the format costs per byte once launches no longer
@@ -352,13 +352,13 @@ def mixed_wave_extra(codec, n=65536, key="c4"):
     cols = codec.columns_from_numpy(fmt, [
         rng.integers(-2**31, 2**31, n).astype(np.int32), rng.integers(0, 2**63, n).astype(np.uint64),
         rng.uniform(-1e6, 1e6, n), (slen, sbody), (alen, rng.integers(0, 256, int(alen.sum()), dtype=np.uint8))])
-    lens, offs, total = codec.sizeof(fmt, cols, n, 16, 0)
+    lens, offs, total = codec.sizeof(fmt, cols, n, align, 0)
     wire = W.WireWave(torch.zeros(total, dtype=torch.uint8, device=dev), n, offs, lens, 0)
     dcols = codec.alloc_columns(fmt, n, capacities=[0, 0, 0, int(slen.sum()), int(alen.sum())])
     ok = torch.empty(n, dtype=torch.int32, device=dev)
 
     def enc():
-        codec.sizeof(fmt, cols, n, 16, 0, want_total=False, lens=lens, offsets=offs)
+        codec.sizeof(fmt, cols, n, align, 0, want_total=False, lens=lens, offsets=offs)
         codec.encode_into(fmt, cols, wire)
 
     def dec():

@@ -302,13 +302,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, Fmt
     const uint64_t s_last = raw.x;
     const uint64_t nseg = s_last - seg + 1;
     __shared__ uint64_t s_lo[COPY_LDS_SEGS + 1];
-    __shared__ uint8_t *s_wire[COPY_LDS_SEGS];
+    __shared__ uint64_t s_woff[COPY_LDS_SEGS];      // arena offsets (an address read back from LDS would
+                                                    // compile to flat accesses)
     if (nseg <= COPY_LDS_SEGS) {
         for (uint32_t i = threadIdx.x; i < nseg; i += MRPDR_TPB) {
             Seg t;
             seg_load(t, seg + i, W, a, fmt, cols);
             s_lo[i] = t.lo;
-            s_wire[i] = t.wire;
+            s_woff[i] = (uint64_t)(t.wire - a.wire.base);
             if (i + 1 == nseg) s_lo[nseg] = t.hi;
         }
         __syncthreads();
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, Fmt
             }
             at[u] = lo;
             whole[u] = b + COPY_PIECE <= ce && b + COPY_PIECE <= s_lo[lo + 1];
-            if (whole[u]) v[u] = ENCODE ? ld16<false>(a.dense + b) : ld16_any<false>(s_wire[lo] + (b - s_lo[lo]));
+            if (whole[u]) v[u] = ENCODE ? ld16<false>(a.dense + b) : ld16_any<false>(fa.wire_base + s_woff[lo] + (b - s_lo[lo]));
         }
 #pragma unroll
         for (int u = 0; u < COPY_UNROLL; u++) {
@@ -337,13 +338,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_copy(CopyFast fa, CopyArgs a, Fmt
             if (b >= ce) continue;
             uint32_t lo = at[u];
             if (whole[u]) {
-                if (ENCODE) st16_any<false>(s_wire[lo] + (b - s_lo[lo]), v[u]);
+                if (ENCODE) st16_any<false>(fa.wire_base + s_woff[lo] + (b - s_lo[lo]), v[u]);
                 else        st16<false>(a.dense + b, SWAP ? swap_elems<W>(v[u]) : v[u]);
             } else {
                 const uint64_t e = (b + COPY_PIECE < ce) ? b + COPY_PIECE : ce;
                 for (uint64_t p = b; p < e; p += W) {
                     while (p >= s_lo[lo + 1]) lo++;             // next packet (skips empty arrays)
-                    uint8_t *wp = s_wire[lo] + (p - s_lo[lo]);
+                    uint8_t *wp = fa.wire_base + s_woff[lo] + (p - s_lo[lo]);
                     if (ENCODE) {
                         st_u<U>(wp, ld_u<U>(a.dense + p));
                     } else {

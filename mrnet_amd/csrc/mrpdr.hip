@@ -138,7 +138,7 @@ extern "C" mrpdr_fmt *mrpdr_fmt_compile(const char *fmt)
         if (fd.kind == MRPDR_SCALAR) fixed += fd.width;
         else {
             fixed += prefix_bytes(fd.kind);
-            if (f->nvar < TILE_MAXV) f->tv.field[f->nvar] = f->dev.nf - 1;
+            if (f->nvar < TILE_MAXV) { f->tv.field[f->nvar] = f->dev.nf - 1; f->tv.width[f->nvar] = fd.width; }
             f->nvar++;
             f->nstrarr += fd.kind == MRPDR_STRING_ARRAY;
         }

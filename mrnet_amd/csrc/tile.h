@@ -30,10 +30,12 @@
 #define TILE_MAXV 8
 #define TILE_IMG (24 * 1024)
 #define TILE_OFFS_PKTS 1024            // packets per workgroup of k_tile_offs
+static_assert(TILE_PKTS == 64, "the tile kernels give every packet of a tile one lane of a wavefront");
 
 struct TileVars {                       // the variable fields of the format, in order
     int32_t nv;
     int32_t field[TILE_MAXV];
+    int32_t width[TILE_MAXV];           // element width of each (kept here: one scalar load, no chain)
 };
 
 // MAXV = variable fields the tables hold: formats with up to 4 take the small form, which leaves
@@ -45,6 +47,7 @@ struct TileLdsT {
     uint64_t seg[MAXV][TILE_PKTS + 1];  // offs[] of every variable field, in elements
     uint64_t vpos[MAXV][TILE_PKTS];     // position of the field's length prefix in its packet
     int32_t  staged;
+    int32_t  packed;                    // every packet starts where the one before it ends
 };
 #define TILE_SMALLV 4
 
@@ -74,7 +77,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
                                                const ColsDev &cols, uint64_t p0, uint32_t np)
 {
     const uint32_t t = threadIdx.x;
-    if (t == 0) m.staged = 1;
+    if (t == 0) { m.staged = 1; m.packed = 1; }
     if (t < np) {
         const uint64_t s = wire.offsets[p0 + t], l = wire.lens[p0 + t];
         m.start[t] = s;
@@ -90,18 +93,19 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         if (t + 1 < np && m.start[t + 1] < e) fine = false;                    // in order, no overlap
         if (t == 0 && (m.end[np - 1] < s || m.end[np - 1] - s + 32 > TILE_IMG)) fine = false;   // fits the image
         if (!fine) m.staged = 0;
+        if (t + 1 < np && m.start[t + 1] != e) m.packed = 0;
     }
     __syncthreads();
 }
 
 // Bytes of the variable fields in front of field f in packet i of the tile.
 template <typename L>
-__device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &tv, const FmtDev &fmt,
+__device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &tv, const FmtDev &,
                                                     int f, uint32_t i)
 {
     uint64_t b = 0;
     for (int v = 0; v < tv.nv && tv.field[v] < f; v++)
-        b += (m.seg[v][i + 1] - m.seg[v][i]) * (uint64_t)fmt.f[tv.field[v]].width;
+        b += (m.seg[v][i + 1] - m.seg[v][i]) * (uint64_t)tv.width[v];
     return b;
 }
 
@@ -156,19 +160,22 @@ __device__ __forceinline__ void tile_fill_field(L &m, uint8_t *img, int v, uint3
     typedef typename UIntOf<W>::type U;
     constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
-    uint8_t *w[PK];
-    const uint8_t *d[PK];
+    // Positions are kept as offsets from the image and from the column, not as pointers: the
+    // accesses then compile to LDS and global instructions (pointers that pass through an
+    // array of generic pointers end up as flat accesses).
+    uint32_t wo[PK];
+    uint64_t dof[PK];
     uint32_t len[PK];
     bool more = false;
 #pragma unroll
     for (int k = 0; k < PK; k++) {
         const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
-        len[k] = 0; w[k] = img; d[k] = dense;
+        len[k] = 0; wo[k] = 0; dof[k] = 0;
         if (i < np) {
             const uint64_t s_lo = m.seg[v][i] * W;
             len[k] = (uint32_t)(m.seg[v][i + 1] * W - s_lo);      // a staged tile holds less than 24 KiB
-            w[k] = tile_at<true>(img, nullptr, lo, mis, m.start[i] + m.vpos[v][i] + pre);
-            d[k] = dense + s_lo;
+            wo[k] = (uint32_t)(m.start[i] + m.vpos[v][i] + pre - lo) + mis;
+            dof[k] = s_lo;
             more |= len[k] > 512u;
         }
     }
@@ -178,29 +185,30 @@ __device__ __forceinline__ void tile_fill_field(L &m, uint8_t *img, int v, uint3
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const uint32_t o = lane * 16u + (uint32_t)q * 256u;
-            if (o + 16u <= len[k]) r[k][q] = ld16_any<false>(d[k] + o);
+            if (o + 16u <= len[k]) r[k][q] = ld16_any<false>(dense + dof[k] + o);
         }
     U tail[PK];
 #pragma unroll
     for (int k = 0; k < PK; k++) {
         const uint32_t o = (len[k] & ~15u) + lane * W;
-        if (o < len[k]) tail[k] = ld_u<U>(d[k] + o);
+        if (o < len[k]) tail[k] = ld_u<U>(dense + dof[k] + o);
     }
 #pragma unroll
     for (int k = 0; k < PK; k++) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
             const uint32_t o = lane * 16u + (uint32_t)q * 256u;
-            if (o + 16u <= len[k]) st16_u(w[k] + o, r[k][q]);
+            if (o + 16u <= len[k]) st16_u(img + wo[k] + o, r[k][q]);
         }
         const uint32_t o = (len[k] & ~15u) + lane * W;
-        if (o < len[k]) st_u<U>(w[k] + o, tail[k]);
+        if (o < len[k]) st_u<U>(img + wo[k] + o, tail[k]);
     }
     if (!more) return;
     // payloads beyond 512 bytes: the remaining whole pieces, one at a time
 #pragma unroll
     for (int k = 0; k < PK; k++)
-        for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u) st16_u(w[k] + o, ld16_any<false>(d[k] + o));
+        for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u)
+            st16_u(img + wo[k] + o, ld16_any<false>(dense + dof[k] + o));
 }
 
 template <bool STAGED, bool ENCODE, bool SWAP, int W, typename L>
@@ -257,42 +265,30 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     const uint32_t t = threadIdx.x;
     const uint64_t lo = m.start[0];
     const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+    // One wavefront per field, one lane per packet: what depends on the field alone (its
+    // kind, width, column) is the same for all lanes, so it is fetched by scalar loads and the
+    // branches on it do not diverge; the column reads of a wavefront are one contiguous run.
+    const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint32_t i = t & 63u;
     // where every variable field starts in its packet
-    for (uint32_t idx = t; idx < (uint32_t)tv.nv * np; idx += MRPDR_TPB) {
-        const int v = (int)(idx / np);
-        const uint32_t i = idx - (uint32_t)v * np;
-        m.vpos[v][i] = fmt.f[tv.field[v]].fixed_before + tile_var_before(m, tv, fmt, tv.field[v], i);
+    for (int v = wv; v < tv.nv; v += MRPDR_TPB / 64) {
+        const int f = tv.field[v];
+        if (i < np) m.vpos[v][i] = fmt.f[f].fixed_before + tile_var_before(m, tv, fmt, f, i);
     }
-    // scalars and length prefixes: one (field, packet) pair per thread, field-major so that the
-    // column reads of neighbouring lanes are neighbours
-    // (two pairs per trip: both column loads are issued before the first store)
-    for (uint32_t idx0 = t; idx0 < (uint32_t)fmt.nf * np; idx0 += 2 * MRPDR_TPB) {
-        uint64_t val[2];
-        uint8_t *dst[2];
-        uint32_t wid[2];
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t idx = idx0 + (uint32_t)q * MRPDR_TPB;
-            wid[q] = 0; val[q] = 0; dst[q] = nullptr;
-            if (idx >= (uint32_t)fmt.nf * np) continue;
-            const int f = (int)(idx / np);
-            const uint32_t i = idx - (uint32_t)f * np;
-            const FieldDev fd = fmt.f[f];
-            const uint64_t pos = fd.fixed_before + tile_var_before(m, tv, fmt, f, i);
-            dst[q] = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + pos);
-            if (fd.kind == MRPDR_SCALAR) {
-                wid[q] = fd.width;
-                val[q] = ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + (p0 + i) * fd.width, (int)fd.width, false);
-            } else {
-                int v = 0;
-                while (tv.field[v] != f) v++;
-                val[q] = m.seg[v][i + 1] - m.seg[v][i];
-                wid[q] = fd.kind == MRPDR_ARRAY ? 8u : 4u;   // pdr_uint64(count), src/pdr.c:425; strlen+1, :295-297
-            }
+    // scalars and length prefixes
+    for (int f = wv; f < fmt.nf; f += MRPDR_TPB / 64) {
+        const FieldDev fd = fmt.f[f];
+        if (i >= np) continue;
+        uint8_t *dst = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + fd.fixed_before + tile_var_before(m, tv, fmt, f, i));
+        if (fd.kind == MRPDR_SCALAR) {
+            const uint8_t *src = reinterpret_cast<const uint8_t *>(cols.values[f]) + (p0 + i) * fd.width;
+            st_w(dst, (int)fd.width, ld_wire_w(src, (int)fd.width, false));
+        } else {
+            int v = 0;
+            while (tv.field[v] != f) v++;
+            // pdr_uint64(count), src/pdr.c:425; strlen+1, :295-297
+            st_w(dst, fd.kind == MRPDR_ARRAY ? 8 : 4, m.seg[v][i + 1] - m.seg[v][i]);
         }
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-            if (wid[q]) st_w(dst[q], (int)wid[q], val[q]);
     }
     __syncthreads();
     tile_copy_fields<STAGED, true, false>(m, img, fmt, tv, wire, cols, np);
@@ -302,6 +298,20 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     // boundary and behind the last one go out one per lane, the pieces between them as aligned
     // 128-bit stores.  Only bytes of packets are written: what lies between packets is not ours
     // (padding of the caller's layout, or the headers of a message).
+    if (m.packed) {
+        // the tile is one run of bytes: out as a block, aligned 128-bit stores by all lanes
+        const uint64_t hi = m.end[np - 1];
+        const uint64_t a0 = lo + ((16u - mis) & 15u);
+        const uint64_t head_end = a0 < hi ? a0 : hi;
+        if (lo + t < head_end) wire.base[lo + t] = img[mis + t];
+        if (a0 < hi) {
+            const uint64_t a1 = a0 + ((hi - a0) & ~(uint64_t)15);
+            for (uint64_t x = a0 + (uint64_t)t * 16u; x < a1; x += MRPDR_TPB * 16u)
+                *reinterpret_cast<u32x4 *>(wire.base + x) = *reinterpret_cast<const u32x4 *>(img + (uint32_t)(x - lo) + mis);
+            if (a1 + t < hi) wire.base[a1 + t] = img[(uint32_t)(a1 - lo) + mis + t];
+        }
+        return;
+    }
     const uint32_t grp = t >> 4, lane = t & 15u;
     for (uint32_t i = grp; i < np; i += MRPDR_TPB / 16) {
         const uint64_t s = m.start[i], e = m.end[i];
@@ -443,10 +453,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     }
     // where every variable field starts in its packet, from the counts (a packet that failed
     // has zero counts from the failed field on, so nothing of it is moved)
-    for (uint32_t idx = t; idx < (uint32_t)tv.nv * np; idx += MRPDR_TPB) {
-        const int v = (int)(idx / np);
-        const uint32_t i = idx - (uint32_t)v * np;
-        m.vpos[v][i] = fmt.f[tv.field[v]].fixed_before + tile_var_before(m, tv, fmt, tv.field[v], i);
+    {
+        const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));      // a wavefront per field
+        const uint32_t i = t & 63u;
+        for (int v = wv; v < tv.nv; v += MRPDR_TPB / 64) {
+            const int f = tv.field[v];
+            if (i < np) m.vpos[v][i] = fmt.f[f].fixed_before + tile_var_before(m, tv, fmt, f, i);
+        }
     }
     __syncthreads();
     if (staged) tile_copy_fields<true, false, SWAP>(m, img, fmt, tv, wire, cols, np);

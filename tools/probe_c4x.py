@@ -7,3 +7,5 @@ import bench
 big = W.Codec(max_packets=1 << 20)
 print(bench.mixed_wave_extra(big))
 print(bench.mixed_wave_extra(big, n=1 << 20, key="c4_x16"))
+print(bench.mixed_wave_extra(big, key="c4_packed", align=1))
+print(bench.mixed_wave_extra(big, n=1 << 20, key="c4_x16_packed", align=1))
