@@ -48,6 +48,7 @@ struct TileLdsT {
     uint64_t vpos[MAXV][TILE_PKTS];     // position of the field's length prefix in its packet
     int32_t  staged;
     int32_t  packed;                    // every packet starts where the one before it ends
+    int32_t  too_small;                 // decode: a values column cannot hold the wave
 };
 #define TILE_SMALLV 4
 
@@ -72,12 +73,19 @@ __device__ __forceinline__ void st16_u(uint8_t *p, u32x4 v)
 
 // Packet boundaries (and, with SEGS, the offs[] of the variable fields) of the tile into LDS
 // in one round of global loads; decides whether the tile can be staged.
-template <bool SEGS, typename L>
+// With CAPS the capacities of the values columns are checked against the wave's totals in the
+// same round (offs[n] of every variable field).
+template <bool SEGS, bool CAPS, typename L>
 __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const WireDev &wire,
-                                               const ColsDev &cols, uint64_t p0, uint32_t np)
+                                               const ColsDev &cols, uint64_t p0, uint32_t np, uint64_t n)
 {
     const uint32_t t = threadIdx.x;
-    if (t == 0) { m.staged = 1; m.packed = 1; }
+    if (t == 0) { m.staged = 1; m.packed = 1; m.too_small = 0; }
+    bool over = false;
+    if (CAPS && t >= MRPDR_TPB - TILE_MAXV && (int)(t - (MRPDR_TPB - TILE_MAXV)) < tv.nv) {
+        const int f = tv.field[t - (MRPDR_TPB - TILE_MAXV)];
+        over = cols.offs[f][n] > cols.cap[f];
+    }
     if (t < np) {
         const uint64_t s = wire.offsets[p0 + t], l = wire.lens[p0 + t];
         m.start[t] = s;
@@ -95,6 +103,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         if (!fine) m.staged = 0;
         if (t + 1 < np && m.start[t + 1] != e) m.packed = 0;
     }
+    if (over) m.too_small = 1;
     __syncthreads();
 }
 
@@ -211,12 +220,72 @@ __device__ __forceinline__ void tile_fill_field(L &m, uint8_t *img, int v, uint3
             st16_u(img + wo[k] + o, ld16_any<false>(dense + dof[k] + o));
 }
 
+// Decode out of the image: the mirror of tile_fill_field.  The LDS reads of a lane's four
+// packets are all issued before the first global store, so their latencies overlap.
+template <bool SWAP, int W, typename L>
+__device__ __forceinline__ void tile_drain_field(L &m, const uint8_t *img, int v, uint32_t pre, uint8_t *dense,
+                                                 uint32_t np, uint64_t lo, uint32_t mis)
+{
+    typedef typename UIntOf<W>::type U;
+    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
+    const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
+    uint32_t wo[PK];
+    uint64_t dof[PK];
+    uint32_t len[PK];
+    bool more = false;
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
+        len[k] = 0; wo[k] = 0; dof[k] = 0;
+        if (i < np) {
+            const uint64_t s_lo = m.seg[v][i] * W;
+            len[k] = (uint32_t)(m.seg[v][i + 1] * W - s_lo);      // a staged tile holds less than 24 KiB
+            wo[k] = (uint32_t)(m.start[i] + m.vpos[v][i] + pre - lo) + mis;
+            dof[k] = s_lo;
+            more |= len[k] > 512u;
+        }
+    }
+    u32x4 r[PK][2];
+#pragma unroll
+    for (int k = 0; k < PK; k++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+            if (o + 16u <= len[k]) r[k][q] = ld16_u(img + wo[k] + o);
+        }
+    U tail[PK];
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        const uint32_t o = (len[k] & ~15u) + lane * W;
+        if (o < len[k]) tail[k] = ld_u<U>(img + wo[k] + o);
+    }
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+            if (o + 16u <= len[k]) st16_any<false>(dense + dof[k] + o, SWAP ? swap_elems<W>(r[k][q]) : r[k][q]);
+        }
+        const uint32_t o = (len[k] & ~15u) + lane * W;
+        if (o < len[k]) st_u<U>(dense + dof[k] + o, SWAP ? bswap_u(tail[k]) : tail[k]);
+    }
+    if (!more) return;
+    // payloads beyond 512 bytes: the remaining whole pieces, one at a time
+#pragma unroll
+    for (int k = 0; k < PK; k++)
+        for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u) {
+            const u32x4 x = ld16_u(img + wo[k] + o);
+            st16_any<false>(dense + dof[k] + o, SWAP ? swap_elems<W>(x) : x);
+        }
+}
+
 template <bool STAGED, bool ENCODE, bool SWAP, int W, typename L>
 __device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
                                                 uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
 {
-    if (STAGED && ENCODE) {
-        tile_fill_field<W>(m, img, v, pre, dense, np, lo, mis);
+    if (STAGED) {
+        if (ENCODE) tile_fill_field<W>(m, img, v, pre, dense, np, lo, mis);
+        else        tile_drain_field<SWAP, W>(m, img, v, pre, dense, np, lo, mis);
         return;
     }
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
@@ -336,7 +405,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars 
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
-    tile_load_meta<true>(m, tv, wire, cols, p0, np);
+    tile_load_meta<true, false>(m, tv, wire, cols, p0, np, n);
     if (m.staged) tile_encode_body<true>(m, img, fmt, tv, wire, cols, p0, np);
     else          tile_encode_body<false>(m, img, fmt, tv, wire, cols, p0, np);
 }
@@ -354,7 +423,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
-    tile_load_meta<false>(m, tv, wire, cols, p0, np);
+    tile_load_meta<false, false>(m, tv, wire, cols, p0, np, n);
     const bool staged = m.staged != 0;
     const uint64_t lo = m.start[0];
     const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
@@ -433,16 +502,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
 {
     __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
-    __shared__ int32_t too_small;
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
     // a column too small for the wave: nothing is written, the status word says so
-    if (t == 0) too_small = 0;
-    __syncthreads();
-    if (t < (uint32_t)tv.nv && cols.offs[tv.field[t]][n] > cols.cap[tv.field[t]]) too_small = 1;
-    tile_load_meta<true>(m, tv, wire, cols, p0, np);
-    if (too_small) {
+    tile_load_meta<true, true>(m, tv, wire, cols, p0, np, n);
+    if (m.too_small) {
         if (blockIdx.x == 0 && t == 0) atomicOr(status, 1u);
         return;
     }
