@@ -42,6 +42,7 @@ struct TileVars {                       // the variable fields of the format, in
 // room for a fifth workgroup per CU (measured on a 1M-packet wave: +11 % throughput).
 template <int MAXV>
 struct TileLdsT {
+    static constexpr int NV = MAXV;
     uint64_t start[TILE_PKTS + 1];      // arena offset of every packet of the tile
     uint64_t end[TILE_PKTS];
     uint64_t seg[MAXV][TILE_PKTS + 1];  // offs[] of every variable field, in elements
@@ -86,14 +87,23 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         const int f = tv.field[t - (MRPDR_TPB - TILE_MAXV)];
         over = cols.offs[f][n] > cols.cap[f];
     }
-    if (t < np) {
-        const uint64_t s = wire.offsets[p0 + t], l = wire.lens[p0 + t];
-        m.start[t] = s;
-        m.end[t] = s + l;
+    // every load of the round is issued before the first LDS store waits for one of them
+    uint64_t s0 = 0, l0 = 0;
+    if (t < np) { s0 = wire.offsets[p0 + t]; l0 = wire.lens[p0 + t]; }
+    uint64_t sg[L::NV];
+    if (SEGS) {
+#pragma unroll
+        for (int v = 0; v < L::NV; v++) sg[v] = (v < tv.nv && t <= np) ? cols.offs[tv.field[v]][p0 + t] : 0;
     }
-    if (SEGS)
-        for (int v = 0; v < tv.nv; v++)
-            for (uint32_t k = t; k <= np; k += MRPDR_TPB) m.seg[v][k] = cols.offs[tv.field[v]][p0 + k];
+    if (t < np) {
+        m.start[t] = s0;
+        m.end[t] = s0 + l0;
+    }
+    if (SEGS) {
+#pragma unroll
+        for (int v = 0; v < L::NV; v++)
+            if (v < tv.nv && t <= np) m.seg[v][t] = sg[v];
+    }
     __syncthreads();
     if (t < np) {
         const uint64_t s = m.start[t], e = m.end[t];
@@ -158,69 +168,79 @@ __device__ __forceinline__ void tile_copy_run(uint8_t *w, uint8_t *d, uint64_t l
     }
 }
 
-// Encode into the image: the same packet-by-packet copy with the global loads of a lane's four
-// packets (two 128-bit pieces each, then one tail element each) all issued before the first LDS
-// store.  A lane waits for memory twice per field instead of once per piece: the loads are
-// what the staged encode spends its time on, the stores go to LDS.
-template <int W, typename L>
-__device__ __forceinline__ void tile_fill_field(L &m, uint8_t *img, int v, uint32_t pre, const uint8_t *dense,
-                                                uint32_t np, uint64_t lo, uint32_t mis)
-{
-    typedef typename UIntOf<W>::type U;
-    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
-    const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
-    // Positions are kept as offsets from the image and from the column, not as pointers: the
-    // accesses then compile to LDS and global instructions (pointers that pass through an
-    // array of generic pointers end up as flat accesses).
+// Encode into the image: the same packet-by-packet copy, split in two.  load() issues the global
+// loads of a lane's four packets (two 128-bit pieces each, then one tail byte each); store()
+// puts them into the image.  Nothing is reversed on encode (src/pdr_mem.c:22-38 and its twins
+// store native order), so the copy is a copy of bytes whatever the element width, and one body
+// serves all fields.  Between the two calls the lane can do other work: its wait for memory
+// then covers both.  Positions are kept as offsets from the image and from the column, not as
+// pointers: the accesses then compile to LDS and global instructions (pointers that pass
+// through an array of generic pointers end up as flat accesses).
+struct TileFill {
+    static constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
     uint32_t wo[PK];
     uint64_t dof[PK];
     uint32_t len[PK];
-    bool more = false;
-#pragma unroll
-    for (int k = 0; k < PK; k++) {
-        const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
-        len[k] = 0; wo[k] = 0; dof[k] = 0;
-        if (i < np) {
-            const uint64_t s_lo = m.seg[v][i] * W;
-            len[k] = (uint32_t)(m.seg[v][i + 1] * W - s_lo);      // a staged tile holds less than 24 KiB
-            wo[k] = (uint32_t)(m.start[i] + m.vpos[v][i] + pre - lo) + mis;
-            dof[k] = s_lo;
-            more |= len[k] > 512u;
-        }
-    }
     u32x4 r[PK][2];
-#pragma unroll
-    for (int k = 0; k < PK; k++)
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
-            if (o + 16u <= len[k]) r[k][q] = ld16_any<false>(dense + dof[k] + o);
-        }
-    U tail[PK];
-#pragma unroll
-    for (int k = 0; k < PK; k++) {
-        const uint32_t o = (len[k] & ~15u) + lane * W;
-        if (o < len[k]) tail[k] = ld_u<U>(dense + dof[k] + o);
-    }
-#pragma unroll
-    for (int k = 0; k < PK; k++) {
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t o = lane * 16u + (uint32_t)q * 256u;
-            if (o + 16u <= len[k]) st16_u(img + wo[k] + o, r[k][q]);
-        }
-        const uint32_t o = (len[k] & ~15u) + lane * W;
-        if (o < len[k]) st_u<U>(img + wo[k] + o, tail[k]);
-    }
-    if (!more) return;
-    // payloads beyond 512 bytes: the remaining whole pieces, one at a time
-#pragma unroll
-    for (int k = 0; k < PK; k++)
-        for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u)
-            st16_u(img + wo[k] + o, ld16_any<false>(dense + dof[k] + o));
-}
+    uint8_t tail[PK];
+    bool more;
 
-// Decode out of the image: the mirror of tile_fill_field.  The LDS reads of a lane's four
+    // vpos_of(i) = where the field's length prefix starts in packet i
+    template <typename L, typename VPOS>
+    __device__ __forceinline__ void load(const L &m, int v, uint32_t width, uint32_t pre, const uint8_t *dense,
+                                         uint32_t np, uint64_t lo, uint32_t mis, VPOS vpos_of)
+    {
+        const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
+        more = false;
+#pragma unroll
+        for (int k = 0; k < PK; k++) {
+            const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
+            len[k] = 0; wo[k] = 0; dof[k] = 0;
+            if (i < np) {
+                const uint64_t s_lo = m.seg[v][i] * width;
+                len[k] = (uint32_t)(m.seg[v][i + 1] * width - s_lo);      // a staged tile holds less than 24 KiB
+                wo[k] = (uint32_t)(m.start[i] + vpos_of(i) + pre - lo) + mis;
+                dof[k] = s_lo;
+                more |= len[k] > 512u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PK; k++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+                if (o + 16u <= len[k]) r[k][q] = ld16_any<false>(dense + dof[k] + o);
+            }
+#pragma unroll
+        for (int k = 0; k < PK; k++) {
+            const uint32_t o = (len[k] & ~15u) + lane;
+            if (o < len[k]) tail[k] = dense[dof[k] + o];
+        }
+    }
+
+    __device__ __forceinline__ void store(uint8_t *img, const uint8_t *dense) const
+    {
+        const uint32_t lane = threadIdx.x & 15u;
+#pragma unroll
+        for (int k = 0; k < PK; k++) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t o = lane * 16u + (uint32_t)q * 256u;
+                if (o + 16u <= len[k]) st16_u(img + wo[k] + o, r[k][q]);
+            }
+            const uint32_t o = (len[k] & ~15u) + lane;
+            if (o < len[k]) img[wo[k] + o] = tail[k];
+        }
+        if (!more) return;
+        // payloads beyond 512 bytes: the remaining whole pieces, one at a time
+#pragma unroll
+        for (int k = 0; k < PK; k++)
+            for (uint32_t o = 512u + lane * 16u; o + 16u <= len[k]; o += 256u)
+                st16_u(img + wo[k] + o, ld16_any<false>(dense + dof[k] + o));
+    }
+};
+
+// Decode out of the image: the mirror of TileFill in one piece.  The LDS reads of a lane's four
 // packets are all issued before the first global store, so their latencies overlap.
 template <bool SWAP, int W, typename L>
 __device__ __forceinline__ void tile_drain_field(L &m, const uint8_t *img, int v, uint32_t pre, uint8_t *dense,
@@ -283,9 +303,8 @@ template <bool STAGED, bool ENCODE, bool SWAP, int W, typename L>
 __device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
                                                 uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
 {
-    if (STAGED) {
-        if (ENCODE) tile_fill_field<W>(m, img, v, pre, dense, np, lo, mis);
-        else        tile_drain_field<SWAP, W>(m, img, v, pre, dense, np, lo, mis);
+    if (STAGED && !ENCODE) {        // (the staged encode is driven by tile_encode_body itself)
+        tile_drain_field<SWAP, W>(m, img, v, pre, dense, np, lo, mis);
         return;
     }
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
@@ -334,6 +353,18 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     const uint32_t t = threadIdx.x;
     const uint64_t lo = m.start[0];
     const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+    // The payload of the first variable field starts at a fixed place in every packet (only
+    // scalars lie in front of it), so its loads need nothing but the tile's offs[]: they are
+    // issued first and are on their way while the scalars are handled.
+    TileFill fill;
+    const uint8_t *dense0 = nullptr;
+    if (STAGED && tv.nv > 0) {
+        const int f = tv.field[0];
+        const uint64_t at0 = fmt.f[f].fixed_before;
+        dense0 = reinterpret_cast<const uint8_t *>(cols.values[f]);
+        fill.load(m, 0, (uint32_t)tv.width[0], prefix_bytes(fmt.f[f].kind), dense0, np, lo, mis,
+                  [at0](uint32_t) { return at0; });
+    }
     // One wavefront per field, one lane per packet: what depends on the field alone (its
     // kind, width, column) is the same for all lanes, so it is fetched by scalar loads and the
     // branches on it do not diverge; the column reads of a wavefront are one contiguous run.
@@ -359,9 +390,20 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
             st_w(dst, fd.kind == MRPDR_ARRAY ? 8 : 4, m.seg[v][i + 1] - m.seg[v][i]);
         }
     }
-    __syncthreads();
-    tile_copy_fields<STAGED, true, false>(m, img, fmt, tv, wire, cols, np);
-    if (!STAGED) return;
+    if (!STAGED) {
+        __syncthreads();
+        tile_copy_fields<false, true, false>(m, img, fmt, tv, wire, cols, np);
+        return;
+    }
+    if (tv.nv > 0) fill.store(img, dense0);
+    __syncthreads();                     // the positions of the other variable fields are in LDS
+    for (int v = 1; v < tv.nv; v++) {
+        const int f = tv.field[v];
+        const uint8_t *dense = reinterpret_cast<const uint8_t *>(cols.values[f]);
+        fill.load(m, v, (uint32_t)tv.width[v], prefix_bytes(fmt.f[f].kind), dense, np, lo, mis,
+                  [&m, v](uint32_t k) { return m.vpos[v][k]; });
+        fill.store(img, dense);
+    }
     __syncthreads();
     // image -> arena, packet by packet (16 lanes each): the bytes in front of the first 16-byte
     // boundary and behind the last one go out one per lane, the pieces between them as aligned
