@@ -30,6 +30,7 @@
 #define TILE_MAXV 8
 #define TILE_IMG (24 * 1024)
 #define TILE_OFFS_PKTS 1024            // packets per workgroup of k_tile_offs
+static_assert(TILE_IMG % (MRPDR_TPB * 16) == 0, "the image is a whole number of workgroup-wide rows of 16-byte pieces");
 static_assert(TILE_PKTS == 64, "the tile kernels give every packet of a tile one lane of a wavefront");
 
 struct TileVars {                       // the variable fields of the format, in order
@@ -52,6 +53,8 @@ struct TileLdsT {
     int32_t  too_small;                 // decode: a values column cannot hold the wave
 };
 #define TILE_SMALLV 4
+// LDS lets five workgroups (one wavefront each per SIMD) share a CU: the register budget follows.
+#define TILE_WAVES_PER_SIMD 5
 
 // Address of arena byte x: in the LDS image (the image keeps the global address modulo 16, so
 // aligned 128-bit pieces of global memory are aligned pieces of the image) or in the arena.
@@ -130,13 +133,29 @@ __device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &
 
 // Copy of the tile's wire range into the image: aligned 128-bit pieces (the few bytes in front
 // of the first packet and behind the last one that share their 16-byte granule come along).
-// (Issuing all loads of a lane before its first store was measured: slower, it costs occupancy.)
+// A lane has at most TILE_IMG / (MRPDR_TPB * 16) = 6 pieces; their loads are all issued before
+// the first LDS store, so the lane waits for memory once, not once per piece.  (As compiled
+// before, load - wait - store per piece, a 19 KiB tile cost five round trips in a row.)
 __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase, uint64_t lo, uint64_t hi, uint32_t mis)
 {
+    constexpr int PIECES = TILE_IMG / (MRPDR_TPB * 16);
     const uint8_t *g = gbase + lo - mis;
-    const uint32_t bytes = (uint32_t)(hi - lo) + mis;
-    for (uint32_t o = threadIdx.x * 16u; o < bytes; o += MRPDR_TPB * 16u)
-        *reinterpret_cast<u32x4 *>(img + o) = *reinterpret_cast<const u32x4 *>(g + o);
+    const uint32_t bytes = (uint32_t)(hi - lo) + mis;          // at most TILE_IMG - 16 (see tile_load_meta)
+    if (bytes == 0) return;
+    // loads are unconditional (a lane past the end re-reads the last piece): predicated loads
+    // compile to a branch and a wait each, which is the chain this is here to avoid
+    const uint32_t last = (bytes - 1u) & ~15u;
+    u32x4 x[PIECES];
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+        x[k] = *reinterpret_cast<const u32x4 *>(g + (o < last ? o : last));
+    }
+#pragma unroll
+    for (int k = 0; k < PIECES; k++) {
+        const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+        if (o < bytes) *reinterpret_cast<u32x4 *>(img + o) = x[k];
+    }
 }
 
 // Payload of variable field v between the image (or the arena) and the values column, packet by
