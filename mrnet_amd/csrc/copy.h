@@ -81,6 +81,8 @@ struct CopyArgs {
     uint64_t first_chunk;      // chunk index of descriptor 0 (windows of very large columns)
     uint32_t *status;          // bit 0 set when the column is too small
     int32_t  field;
+    uint32_t pos_fixed;        // fixed bytes in front of the field's payload (scalars, prefixes, its own prefix)
+    uint32_t var_before;       // bit g set: field g is variable and lies in front of it
 };
 
 // One 16 KiB chunk of the dense side.
@@ -95,16 +97,6 @@ struct ChunkDesc {
 #define DESC_EXTEND 4u     // encode: the last aligned wire piece may run into the next chunk's bytes
 // a full chunk inside one packet with nothing special at either end
 #define DESC_COMMON ((COPY_CHUNK << 3) | DESC_EXTEND | DESC_SINGLE)
-
-// Position of field f's payload inside packet s: fixed part, own prefix, and the
-// payloads of the variable fields in front of it.
-__device__ inline uint64_t payload_pos(const FmtDev &fmt, const ColsDev &cols, int f, uint64_t s)
-{
-    uint64_t pos = (uint64_t)fmt.f[f].fixed_before + prefix_bytes(fmt.f[f].kind);
-    for (int g = 0; g < f; g++)
-        if (fmt.f[g].kind != MRPDR_SCALAR) pos += var_bytes(fmt, cols, g, s);
-    return pos;
-}
 
 // First segment whose dense range ends after element index e (offs[s+1] > e).
 __device__ inline uint64_t seg_find(const uint64_t *offs, uint64_t lo, uint64_t hi, uint64_t e)
@@ -125,10 +117,17 @@ struct Seg {
 __device__ inline void seg_load(Seg &sg, uint64_t s, uint32_t w, const CopyArgs &a, const FmtDev &fmt,
                                 const ColsDev &cols)
 {
+    // what depends on the format alone was worked out on the host (pos_fixed, var_before): a
+    // format whose only variable field is this one needs no look at the format here, and the
+    // three loads below are independent
     sg.s = s;
-    sg.lo = a.seg_offs[s] * w;
-    sg.hi = a.seg_offs[s + 1] * w;
-    sg.wire = a.wire.base + pkt_off(a.wire, s) + payload_pos(fmt, cols, a.field, s);
+    const uint64_t o0 = a.seg_offs[s], o1 = a.seg_offs[s + 1];
+    uint64_t pos = pkt_off(a.wire, s) + a.pos_fixed;
+    for (uint32_t rest = a.var_before; rest; rest &= rest - 1)
+        pos += var_bytes(fmt, cols, __builtin_ctz(rest), s);
+    sg.lo = o0 * w;
+    sg.hi = o1 * w;
+    sg.wire = a.wire.base + pos;
 }
 
 // One lane per chunk: locate it.

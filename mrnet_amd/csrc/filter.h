@@ -210,19 +210,43 @@ __device__ inline Partial tile_node(const T *vals, const int32_t *cnts, int nval
 }
 
 // This lane's packets: values and (with COUNTS) counts; returns how many there are.
+// All loads of the lane (values, counts, byte orders) are issued before the first of them is
+// used: they are unconditional (a lane past the end re-reads the last packet) and the bytes are
+// put in order afterwards.  Written packet by packet with the swap decided at the load, this
+// compiled to one wait per load, up to sixteen memory round trips in a row.
 template <typename T, bool COUNTS>
 __device__ inline int tile_load(const FilterIn &in, T *vals, int32_t *cnts)
 {
+    typedef typename UIntOf<sizeof(T)>::type U;
     const uint64_t first = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)threadIdx.x * FILTER_LEAF;
+    U raw[FILTER_LEAF];
+    uint32_t rawc[FILTER_LEAF];
+    uint8_t ord[FILTER_LEAF];
+    const uint64_t last = in.n - 1;              // the launch has a workgroup only where there are packets
+#pragma unroll
+    for (int k = 0; k < FILTER_LEAF; k++) {
+        const uint64_t i = first + k < last ? first + k : last;
+        raw[k] = ld_u<U>(in.values + i * in.value_stride);
+        rawc[k] = COUNTS ? ld_u<uint32_t>(in.counts + i * in.count_stride) : 1u;
+    }
+    if (in.orders) {
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) ord[k] = in.orders[first + k < last ? first + k : last];
+    } else {
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) ord[k] = in.swap != 0;
+    }
     int nvalid = 0;
 #pragma unroll
     for (int k = 0; k < FILTER_LEAF; k++) {
-        const uint64_t i = first + k;
         vals[k] = T();
         cnts[k] = 1;
-        if (i < in.n) {
-            vals[k] = load_value<T>(in, i);
-            if (COUNTS) cnts[k] = load_count(in, i);
+        if (first + k < in.n) {
+            U r = raw[k];
+            uint32_t c = rawc[k];
+            if (ord[k]) { r = bswap_u(r); c = bswap_u(c); }
+            vals[k] = from_bits<T>((uint64_t)r);
+            if (COUNTS) cnts[k] = (int32_t)c;
             nvalid = k + 1;
         }
     }

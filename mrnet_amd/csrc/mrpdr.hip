@@ -582,6 +582,10 @@ static CopyArgs make_copy_args(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &
     a.status = c->status;
     a.field = field;
     a.first_chunk = 0;
+    a.pos_fixed = f->dev.f[field].fixed_before + prefix_bytes(f->dev.f[field].kind);
+    a.var_before = 0;
+    for (int g = 0; g < field; g++)
+        if (f->dev.f[g].kind != MRPDR_SCALAR) a.var_before |= 1u << g;
     return a;
 }
 
