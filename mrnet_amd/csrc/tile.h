@@ -53,8 +53,6 @@ struct TileLdsT {
     int32_t  too_small;                 // decode: a values column cannot hold the wave
 };
 #define TILE_SMALLV 4
-// LDS lets five workgroups (one wavefront each per SIMD) share a CU: the register budget follows.
-#define TILE_WAVES_PER_SIMD 5
 
 // Address of arena byte x: in the LDS image (the image keeps the global address modulo 16, so
 // aligned 128-bit pieces of global memory are aligned pieces of the image) or in the arena.
@@ -442,21 +440,53 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
         }
         return;
     }
+    // Positions relative to the tile's first byte (32 bits: a staged tile is shorter than the
+    // image); image byte of relative position r is img[r + mis], and r + mis has the alignment
+    // of the arena address.  The LDS reads of a lane's four packets are issued before the first
+    // global store.
+    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);
     const uint32_t grp = t >> 4, lane = t & 15u;
-    for (uint32_t i = grp; i < np; i += MRPDR_TPB / 16) {
-        const uint64_t s = m.start[i], e = m.end[i];
-        if (e == s) continue;
-        const uint64_t a0 = s + ((0 - (uintptr_t)(wire.base + s)) & 15u);      // first boundary at or behind s
-        const uint64_t head_end = a0 < e ? a0 : e;
-        if (s + lane < head_end) wire.base[s + lane] = *tile_at<true>(img, wire.base, lo, mis, s + lane);
-        if (a0 < e) {
-            const uint64_t a1 = a0 + ((e - a0) & ~(uint64_t)15);
-            for (uint64_t x = a0 + lane * 16u; x < a1; x += 256u)
-                *reinterpret_cast<u32x4 *>(wire.base + x) =
-                    *reinterpret_cast<const u32x4 *>(tile_at<true>(img, wire.base, lo, mis, x));
-            if (a1 + lane < e) wire.base[a1 + lane] = *tile_at<true>(img, wire.base, lo, mis, a1 + lane);
-        }
+    uint8_t *out = wire.base + lo;
+    const uint8_t *src = img + mis;
+    uint32_t rs[PK], re[PK], ra0[PK], ra1[PK];
+    bool more = false;
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        const uint32_t i = grp + (uint32_t)k * (MRPDR_TPB / 16);
+        rs[k] = re[k] = 0;
+        if (i < np) { rs[k] = (uint32_t)(m.start[i] - lo); re[k] = (uint32_t)(m.end[i] - lo); }
+        ra0[k] = rs[k] + ((0u - (rs[k] + mis)) & 15u);          // first 16-byte boundary at or behind the start
+        if (ra0[k] > re[k]) ra0[k] = re[k];
+        ra1[k] = ra0[k] + ((re[k] - ra0[k]) & ~15u);
+        more |= ra1[k] - ra0[k] > 512u;
     }
+    uint8_t hb[PK], tb[PK];
+    u32x4 r[PK][2];
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        if (rs[k] + lane < ra0[k]) hb[k] = src[rs[k] + lane];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t x = ra0[k] + lane * 16u + (uint32_t)q * 256u;
+            if (x < ra1[k]) r[k][q] = *reinterpret_cast<const u32x4 *>(src + x);
+        }
+        if (ra1[k] + lane < re[k]) tb[k] = src[ra1[k] + lane];
+    }
+#pragma unroll
+    for (int k = 0; k < PK; k++) {
+        if (rs[k] + lane < ra0[k]) out[rs[k] + lane] = hb[k];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t x = ra0[k] + lane * 16u + (uint32_t)q * 256u;
+            if (x < ra1[k]) *reinterpret_cast<u32x4 *>(out + x) = r[k][q];
+        }
+        if (ra1[k] + lane < re[k]) out[ra1[k] + lane] = tb[k];
+    }
+    if (!more) return;
+#pragma unroll
+    for (int k = 0; k < PK; k++)
+        for (uint32_t x = ra0[k] + 512u + lane * 16u; x < ra1[k]; x += 256u)
+            *reinterpret_cast<u32x4 *>(out + x) = *reinterpret_cast<const u32x4 *>(src + x);
 }
 
 template <int V>
