@@ -570,6 +570,12 @@ static int32_t launch_copy(mrpdr_ctx *c, CopyArgs a, const FmtDev &fmt, const Co
     return 1;
 }
 
+// Rows kernels: four rows per lane for large waves of narrow rows (see rows.h).
+static bool rows_wide(const WireDev &wd, uint64_t n)
+{
+    return wd.stride <= ROWS_WIDE_MAX_STRIDE && n >= ROWS_WIDE_MIN_PACKETS;
+}
+
 static CopyArgs make_copy_args(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
                                uint64_t n)
 {
@@ -623,7 +629,10 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
     // one-kernel paths have nothing to prepare: they run in the finish phase
     if (rows_path_ok(f, wd)) {
         if (!(phases & 2)) return 1;
-        k_rows_encode<<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, ROWS_PER_BLOCK * wd.stride, st>>>(f->dev, wd, cd, n);
+        if (rows_wide(wd, n))
+            k_rows_encode<ROWS_WIDE><<<blocks_for(n, ROWS_PER_BLOCK * ROWS_WIDE), MRPDR_TPB, ROWS_PER_BLOCK * ROWS_WIDE * wd.stride, st>>>(f->dev, wd, cd, n);
+        else
+            k_rows_encode<1><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, ROWS_PER_BLOCK * wd.stride, st>>>(f->dev, wd, cd, n);
         LAUNCHED("k_rows_encode");
         return 1;
     }
@@ -727,9 +736,16 @@ static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, c
     if (f->nstrarr) HIP_OK(hipMemsetAsync(c->sa_bytes, 0, MRPDR_MAXF * sizeof(uint64_t), st));
     if (n) {
         if (rows_path_ok(f, wd)) {
-            const size_t lds = ROWS_PER_BLOCK * wd.stride;
-            if (swap) k_rows_decode<true><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
-            else      k_rows_decode<false><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+            if (rows_wide(wd, n)) {
+                const size_t lds = ROWS_PER_BLOCK * ROWS_WIDE * wd.stride;
+                const uint32_t nb = blocks_for(n, ROWS_PER_BLOCK * ROWS_WIDE);
+                if (swap) k_rows_decode<true, ROWS_WIDE><<<nb, MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+                else      k_rows_decode<false, ROWS_WIDE><<<nb, MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+            } else {
+                const size_t lds = ROWS_PER_BLOCK * wd.stride;
+                if (swap) k_rows_decode<true, 1><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+                else      k_rows_decode<false, 1><<<blocks_for(n, ROWS_PER_BLOCK), MRPDR_TPB, lds, st>>>(f->dev, wd, cd, n, ok);
+            }
             LAUNCHED("k_rows_decode");
         } else if (!orders && tile_path_ok(f, wd, n)) {
             const uint32_t tiles = blocks_for(n, TILE_PKTS);

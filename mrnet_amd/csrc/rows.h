@@ -6,7 +6,7 @@
 // src/pdr_mem.c:22-315) at a running cursor with a bounds check, no padding.
 //
 // Two forms here:
-//   k_rows_*   scalar-only formats in a packed arena: a workgroup stages 256 packet
+//   k_rows_*   scalar-only formats in a packed arena: a workgroup stages 256 (or 1,024) packet
 //              rows in LDS with 128-bit coalesced global accesses and transposes
 //              them to / from the columns
 //   k_walk_*   any format / any arena layout: one lane walks one packet
@@ -16,72 +16,96 @@
 
 #define ROWS_PER_BLOCK MRPDR_TPB
 #define ROWS_MAX_STRIDE 256
+// Large waves of narrow rows: a lane takes ROWS_WIDE rows (t, t + 256, ...), so a workgroup moves
+// 4 KiB and more instead of 1 KiB and its fixed costs are shared by four times the bytes.
+#define ROWS_WIDE 4
+#define ROWS_WIDE_MAX_STRIDE 16          // 16 KiB of LDS per workgroup at most
+#define ROWS_WIDE_MIN_PACKETS (1u << 19) // below, more workgroups matter more than bigger ones
 
 // ---------------------------------------------------------------------------
 // LDS-staged transposition, scalar-only formats, packed arena
 // ---------------------------------------------------------------------------
-template <bool SWAP>
+template <bool SWAP, int R>
 __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode(FmtDev fmt, WireDev wire, ColsDev cols,
                                                            uint64_t n, int32_t *ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
-    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const uint32_t np = (uint32_t)((n - p0) < ROWS_PER_BLOCK ? (n - p0) : ROWS_PER_BLOCK);
+    constexpr uint32_t ROWS = ROWS_PER_BLOCK * R;
+    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS;
+    const uint32_t np = (uint32_t)((n - p0) < ROWS ? (n - p0) : ROWS);
     const uint32_t stride = (uint32_t)wire.stride;
     const uint32_t tile_bytes = np * stride;
     // p0 * stride is a multiple of 256 bytes, so with a 16-byte aligned arena every
-    // 16-byte piece of the tile is an aligned 128-bit load.
+    // 16-byte piece of the tile is an aligned 128-bit load.  Four loads of a lane are issued
+    // before the first LDS store (unconditional: a lane past the end re-reads the last piece).
     const uint8_t *g = wire.base + p0 * (uint64_t)stride;
-    for (uint32_t off = threadIdx.x * 16u; off < tile_bytes; off += MRPDR_TPB * 16u) {
-        if (off + 16u <= tile_bytes) {
-            *reinterpret_cast<uint4 *>(tile + off) = *reinterpret_cast<const uint4 *>(g + off);
-        } else {
-            for (uint32_t b = off; b < tile_bytes; b++) tile[b] = g[b];
+    const uint32_t whole = tile_bytes & ~15u;
+    for (uint32_t base = 0; base < whole; base += 4u * MRPDR_TPB * 16u) {
+        uint4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t off = base + ((uint32_t)u * MRPDR_TPB + threadIdx.x) * 16u;
+            x[u] = *reinterpret_cast<const uint4 *>(g + (off < whole ? off : whole - 16u));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t off = base + ((uint32_t)u * MRPDR_TPB + threadIdx.x) * 16u;
+            if (off < whole) *reinterpret_cast<uint4 *>(tile + off) = x[u];
         }
     }
+    if (whole + threadIdx.x < tile_bytes) tile[whole + threadIdx.x] = g[whole + threadIdx.x];
     __syncthreads();
-    if (threadIdx.x >= np) return;
-    const uint64_t i = p0 + threadIdx.x;
-    const uint8_t *row = tile + threadIdx.x * stride;
-    const uint64_t len = wire.lens ? wire.lens[i] : (uint64_t)fmt.fixed_bytes;
-    const bool sw = pkt_swap(wire, i, SWAP);        // the wave's order, or this packet's own
-    bool good = true;
-    for (int f = 0; f < fmt.nf; f++) {
-        const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
-        uint64_t v = 0;
-        // same test as every pdrmem_get*: width > remaining space -> FALSE
-        if (good && (uint64_t)at + w <= len && at + w <= stride) {
-            if (((at | stride) & (w - 1)) == 0) {                 // naturally aligned in the LDS tile
-                switch (w) {
-                case 1: v = row[at]; break;
-                case 2: v = *reinterpret_cast<const uint16_t *>(row + at); if (sw) v = __builtin_bswap16((uint16_t)v); break;
-                case 4: v = *reinterpret_cast<const uint32_t *>(row + at); if (sw) v = __builtin_bswap32((uint32_t)v); break;
-                default: v = *reinterpret_cast<const uint64_t *>(row + at); if (sw) v = __builtin_bswap64(v); break;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t lr = threadIdx.x + (uint32_t)r * MRPDR_TPB;
+        if (lr >= np) break;
+        const uint64_t i = p0 + lr;
+        const uint8_t *row = tile + lr * stride;
+        const uint64_t len = wire.lens ? wire.lens[i] : (uint64_t)fmt.fixed_bytes;
+        const bool sw = pkt_swap(wire, i, SWAP);        // the wave's order, or this packet's own
+        bool good = true;
+        for (int f = 0; f < fmt.nf; f++) {
+            const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
+            uint64_t v = 0;
+            // same test as every pdrmem_get*: width > remaining space -> FALSE
+            if (good && (uint64_t)at + w <= len && at + w <= stride) {
+                if (((at | stride) & (w - 1)) == 0) {                 // naturally aligned in the LDS tile
+                    switch (w) {
+                    case 1: v = row[at]; break;
+                    case 2: v = *reinterpret_cast<const uint16_t *>(row + at); if (sw) v = __builtin_bswap16((uint16_t)v); break;
+                    case 4: v = *reinterpret_cast<const uint32_t *>(row + at); if (sw) v = __builtin_bswap32((uint32_t)v); break;
+                    default: v = *reinterpret_cast<const uint64_t *>(row + at); if (sw) v = __builtin_bswap64(v); break;
+                    }
+                } else {
+                    for (uint32_t b = 0; b < w; b++) {
+                        const uint32_t src = sw ? (w - 1 - b) : b;    // src/byte_order.c:12-16
+                        v |= (uint64_t)row[at + src] << (8 * b);
+                    }
                 }
             } else {
-                for (uint32_t b = 0; b < w; b++) {
-                    const uint32_t src = sw ? (w - 1 - b) : b;    // src/byte_order.c:12-16
-                    v |= (uint64_t)row[at + src] << (8 * b);
-                }
+                good = false;
             }
-        } else {
-            good = false;
+            st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + i * w, (int)w, v);
         }
-        st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + i * w, (int)w, v);
+        if (ok) ok[i] = good ? 1 : 0;
     }
-    if (ok) ok[i] = good ? 1 : 0;
 }
 
+template <int R>
 __global__ __launch_bounds__(MRPDR_TPB) void k_rows_encode(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
-    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS_PER_BLOCK;
-    const uint32_t np = (uint32_t)((n - p0) < ROWS_PER_BLOCK ? (n - p0) : ROWS_PER_BLOCK);
+    constexpr uint32_t ROWS = ROWS_PER_BLOCK * R;
+    const uint64_t p0 = (uint64_t)blockIdx.x * ROWS;
+    const uint32_t np = (uint32_t)((n - p0) < ROWS ? (n - p0) : ROWS);
     const uint32_t stride = (uint32_t)wire.stride;
     const uint32_t tile_bytes = np * stride;
-    if (threadIdx.x < np) {
-        const uint64_t i = p0 + threadIdx.x;
-        uint8_t *row = tile + threadIdx.x * stride;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const uint32_t lr = threadIdx.x + (uint32_t)r * MRPDR_TPB;
+        if (lr >= np) break;
+        const uint64_t i = p0 + lr;
+        uint8_t *row = tile + lr * stride;
         for (int f = 0; f < fmt.nf; f++) {
             const uint32_t w = fmt.f[f].width, at = fmt.f[f].fixed_before;
             const uint64_t v = ld_wire_w(reinterpret_cast<const uint8_t *>(cols.values[f]) + i * w, (int)w, false);

@@ -589,12 +589,16 @@ def test_array_count_bound_is_flagged_by_sizeof(codec):
 
 
 @pytest.mark.parametrize("fmt_s,n,max_count", [("%d", 65536, 0), ("%d %uld %lf %s %auc", 65536, 300),
-                                               ("%lf %d", 131072, 0), ("%ad %ad %alf", 131072, 8)])
+                                               ("%lf %d", 131072, 0), ("%ad %ad %alf", 131072, 8),
+                                               ("%d", (1 << 19) + 37, 0), ("%lf %d", (1 << 19) + 1023, 0),
+                                               ("%uhd %c", 1 << 19, 0), ("%c", (1 << 19) + 5, 0)])
 def test_baseline_configs_at_full_size(codec, fmt_s, n, max_count):
     """The benchmark's wave shapes at their full packet counts, byte for byte against the oracle:
     65,536 x '%d', 65,536 x the mixed format, one GPU's 131,072-packet shard of the '%lf %d' and
-    of the performance-data wave.  Encode, then decode what a big-endian sender would have sent."""
-    big = W.Codec(device=codec.device.index, max_packets=1 << 18)
+    of the performance-data wave; and packed scalar waves of more than 2^19 packets, which take the
+    four-rows-per-lane form of the rows kernels.  Encode, then decode what a big-endian sender would
+    have sent."""
+    big = W.Codec(device=codec.device.index, max_packets=1 << 20)
     ocols = make_wave(fmt_s, n, 17, max_count=max_count)
     arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
     fmt = W.Format(fmt_s)
