@@ -16,6 +16,14 @@
 //           k_tile_offs     counts + tile sums -> offs[] of every variable field      (begin)
 //           k_tile_decode   wire -> LDS; payloads -> values columns                   (finish)
 //
+// What a tile costs is a chain of dependent memory round trips, not bytes: measured on a wave of
+// 2^20 packets the HBM traffic is the algorithmic traffic and nothing in the memory system is
+// busy, but a wavefront waits for 85 % of its life.  So every round issues all its loads before
+// the first of them is waited for (metadata; the wire image; the column loads of a field, the
+// first field's together with the scalars), what depends on the format alone comes from scalar
+// loads (one wavefront per field, one lane per packet), and conditional loads are avoided
+// where a clamped address will do: a predicated load compiles to a branch and a wait.
+//
 // A tile whose packets do not fit the LDS image (a giant packet among small ones), overlap or
 // are out of order runs the same code straight on global memory: slower, same result.
 // Formats with string arrays or more than TILE_MAXV variable fields take the generic kernels.
