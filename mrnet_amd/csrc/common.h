@@ -91,6 +91,46 @@ __device__ inline uint64_t packet_bytes(const FmtDev &fmt, const ColsDev &cols, 
     return len;
 }
 
+// The same for K consecutive packets first .. first+K-1 of a lane (those below n), field by
+// field: the loads of the K packets are independent and unconditional (a packet past the end
+// re-reads packet n-1), so they are issued together; what depends on the field alone is
+// fetched once.  Packet by packet, every load was followed by its own wait.
+template <int K>
+__device__ inline void packets_bytes(const FmtDev &fmt, const ColsDev &cols, uint64_t first, uint64_t n,
+                                     uint64_t (&len)[K], bool *bad)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++) len[k] = fmt.fixed_bytes;
+    for (int f = 0; f < fmt.nf; f++) {
+        const FieldDev fd = fmt.f[f];
+        if (fd.kind == MRPDR_SCALAR) continue;
+        uint64_t cnt[K], bytes[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) cnt[k] = cols.counts[f][first + k < n ? first + k : n - 1];
+        if (fd.kind == MRPDR_STRING_ARRAY) {
+            uint64_t at[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) at[k] = cols.offs[f][first + k < n ? first + k : n - 1];
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                bytes[k] = 4 * cnt[k] + (cols.sub_offs[f][at[k] + cnt[k]] - cols.sub_offs[f][at[k]]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; k++) bytes[k] = cnt[k] * (uint64_t)fd.width;
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (first + k >= n) continue;
+            len[k] += bytes[k];
+            if (fd.kind == MRPDR_STRING) {
+                if (cnt[k] == 0 || cnt[k] > 0xFFFFFFFEull) *bad = true;      // as in packet_bytes
+            } else if (!fd.large && cnt[k] > (uint64_t)INT32_MAX) {
+                *bad = true;
+            }
+        }
+    }
+}
+
 __device__ inline uint64_t pkt_off(const WireDev &w, uint64_t i)
 {
     return w.offsets ? w.offsets[i] : i * w.stride;

@@ -115,17 +115,18 @@ __global__ __launch_bounds__(SCAN1_TPB) void k_scan_single(const uint64_t *in, F
         const uint64_t first = base + (uint64_t)threadIdx.x * SCAN_IPT;
         uint64_t v[SCAN_IPT];
         uint64_t s = 0;
+        // (n > 0 inside the loop; all loads of the lane are issued before the first is used)
+        if (SIZED) packets_bytes<SCAN_IPT>(fmt, cols, first, n, v, &bad);
+        else {
+#pragma unroll
+            for (int k = 0; k < SCAN_IPT; k++) v[k] = in[first + k < n ? first + k : n - 1];
+        }
 #pragma unroll
         for (int k = 0; k < SCAN_IPT; k++) {
             uint64_t item = 0;
             if (first + k < n) {
-                if (SIZED) {
-                    item = packet_bytes(fmt, cols, first + k, &bad);
-                    lens[first + k] = item;
-                } else {
-                    item = in[first + k];
-                }
-                item = round_up_pow2(item + phase, align);
+                if (SIZED) lens[first + k] = v[k];
+                item = round_up_pow2(v[k] + phase, align);
             }
             v[k] = item;
             s += item;
@@ -155,12 +156,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_size_sums(FmtDev fmt, ColsDev col
     bool bad = false;
     const uint64_t first = (uint64_t)blockIdx.x * SIZE_PKTS + (uint64_t)threadIdx.x * 4;
     uint64_t s = 0;
+    uint64_t item[4];
+    packets_bytes<4>(fmt, cols, first, n, item, &bad);       // the launch has n > 0
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (first + k >= n) break;
-        const uint64_t item = packet_bytes(fmt, cols, first + k, &bad);
-        lens[first + k] = item;
-        s += round_up_pow2(item + phase, align);
+        lens[first + k] = item[k];
+        s += round_up_pow2(item[k] + phase, align);
     }
     if (bad) atomicOr(status, 4u);
     uint64_t total;
