@@ -104,30 +104,29 @@ __device__ inline void packets_bytes(const FmtDev &fmt, const ColsDev &cols, uin
     for (int f = 0; f < fmt.nf; f++) {
         const FieldDev fd = fmt.f[f];
         if (fd.kind == MRPDR_SCALAR) continue;
-        uint64_t cnt[K], bytes[K];
+        uint64_t cnt[K];
 #pragma unroll
         for (int k = 0; k < K; k++) cnt[k] = cols.counts[f][first + k < n ? first + k : n - 1];
         if (fd.kind == MRPDR_STRING_ARRAY) {
-            uint64_t at[K];
 #pragma unroll
-            for (int k = 0; k < K; k++) at[k] = cols.offs[f][first + k < n ? first + k : n - 1];
-#pragma unroll
-            for (int k = 0; k < K; k++)
-                bytes[k] = 4 * cnt[k] + (cols.sub_offs[f][at[k] + cnt[k]] - cols.sub_offs[f][at[k]]);
+            for (int k = 0; k < K; k++) {
+                if (first + k >= n) continue;
+                const uint64_t at = cols.offs[f][first + k];
+                len[k] += 4 * cnt[k] + (cols.sub_offs[f][at + cnt[k]] - cols.sub_offs[f][at]);
+            }
         } else {
 #pragma unroll
-            for (int k = 0; k < K; k++) bytes[k] = cnt[k] * (uint64_t)fd.width;
+            for (int k = 0; k < K; k++)
+                if (first + k < n) len[k] += cnt[k] * (uint64_t)fd.width;
         }
+        bool wrong = false;
 #pragma unroll
         for (int k = 0; k < K; k++) {
             if (first + k >= n) continue;
-            len[k] += bytes[k];
-            if (fd.kind == MRPDR_STRING) {
-                if (cnt[k] == 0 || cnt[k] > 0xFFFFFFFEull) *bad = true;      // as in packet_bytes
-            } else if (!fd.large && cnt[k] > (uint64_t)INT32_MAX) {
-                *bad = true;
-            }
+            if (fd.kind == MRPDR_STRING) wrong |= cnt[k] == 0 || cnt[k] > 0xFFFFFFFEull;      // as in packet_bytes
+            else if (!fd.large) wrong |= cnt[k] > (uint64_t)INT32_MAX;
         }
+        if (wrong) *bad = true;
     }
 }
 
