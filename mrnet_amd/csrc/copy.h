@@ -108,6 +108,37 @@ __device__ inline uint64_t seg_find(const uint64_t *offs, uint64_t lo, uint64_t 
     return lo;
 }
 
+// The same over all n segments, starting from a guess: the packets of a wave are often all
+// alike, and then the packet of element e is e * n / total.  Two probes (one round trip) settle
+// that case; otherwise the bracket is widened in doubling steps from the guess and the binary
+// search runs inside it.  offs[0] = 0 and e < total = offs[n].
+__device__ inline uint64_t seg_find_near(const uint64_t *offs, uint64_t n, uint64_t total, uint64_t e)
+{
+    uint64_t g = (uint64_t)((double)e * (double)n / (double)total);
+    if (g > n - 1) g = n - 1;
+    const uint64_t a = offs[g], b = offs[g + 1];
+    if (a <= e && e < b) return g;          // no segment in front of g ends after e: offs[g] <= e
+    uint64_t lo, hi, step = 1;
+    if (e < a) {                            // in front of g (g > 0, as offs[0] <= e)
+        hi = g - 1;                         // kept true: offs[hi + 1] > e
+        for (;;) {
+            lo = hi + 1 >= step ? hi + 1 - step : 0;
+            if (lo == 0 || offs[lo] <= e) break;
+            hi = lo - 1;
+            step <<= 1;
+        }
+    } else {                                // behind g
+        lo = g + 1;                         // kept true: offs[lo] <= e
+        for (;;) {
+            hi = lo + step - 1 < n - 1 ? lo + step - 1 : n - 1;
+            if (hi == n - 1 || offs[hi + 1] > e) break;
+            lo = hi + 1;
+            step <<= 1;
+        }
+    }
+    return seg_find(offs, lo, hi, e);
+}
+
 struct Seg {
     uint64_t s;          // segment (= packet) index
     uint64_t lo, hi;     // dense byte range
@@ -145,7 +176,8 @@ __device__ __forceinline__ void plan_chunk(const CopyArgs &a, const FmtDev &fmt,
                                            ChunkDesc *desc, uint64_t k)
 {
     const uint32_t w = fmt.f[a.field].width;
-    const uint64_t total = a.seg_offs[a.n] * w;
+    const uint64_t total_elems = a.seg_offs[a.n];
+    const uint64_t total = total_elems * w;
     ChunkDesc d;
     d.wire_off = 0; d.seg = 0; d.info = 0;
     const uint64_t cb = (a.first_chunk + k) * COPY_CHUNK;
@@ -154,13 +186,13 @@ __device__ __forceinline__ void plan_chunk(const CopyArgs &a, const FmtDev &fmt,
     } else if (cb < total) {
         const uint64_t ce = (cb + COPY_CHUNK < total) ? cb + COPY_CHUNK : total;
         Seg sg;
-        seg_load(sg, seg_find(a.seg_offs, 0, a.n - 1, cb / w), w, a, fmt, cols);
+        seg_load(sg, seg_find_near(a.seg_offs, a.n, total_elems, cb / w), w, a, fmt, cols);
         d.wire_off = (uint64_t)(sg.wire - a.wire.base) + (cb - sg.lo);
         d.seg = (uint32_t)sg.s;
         uint32_t flags = ce <= sg.hi ? DESC_SINGLE : 0u;
         const uint32_t delta = (uint32_t)(0 - (uintptr_t)(a.wire.base + d.wire_off)) & 15u;
         // a chunk that spans packets has no single wire address: the slot carries its last packet
-        if (!flags) d.wire_off = seg_find(a.seg_offs, sg.s, a.n - 1, (ce - 1) / w);
+        if (!flags) d.wire_off = seg_find_near(a.seg_offs, a.n, total_elems, (ce - 1) / w);
         if (!ENCODE || delta == 0) {
             flags |= DESC_EXTEND;
         } else if (flags && ce - cb == COPY_CHUNK) {
