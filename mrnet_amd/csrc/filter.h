@@ -476,12 +476,17 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
         // leaves the serial loop below with the fold alone.
         uint32_t my_ranks = 0;
         uint64_t my_len = 0;
+        // (the four loads are unconditional, a lane past the end re-reads the tile's last packet:
+        // they are issued together, and only the rank itself is a second, dependent round trip)
+        const uint64_t pi = p0 + (t < np ? t : np - 1);
+        const uint64_t ld_len = in.data_counts[pi], ld_off = in.data_offs[pi];
+        const uint64_t ld_rc = in.rank_counts[pi], ld_ro = in.rank_offs[pi];
         if (t < np) {
-            const uint64_t len = in.data_counts[p0 + t];
+            const uint64_t len = ld_len;
             s_len[t] = len;
-            s_off[t] = in.data_offs[p0 + t];
+            s_off[t] = ld_off;
             int32_t rank = 0;
-            if (len && in.rank_counts[p0 + t]) rank = in.rank_vals[in.rank_offs[p0 + t]];
+            if (len && ld_rc) rank = in.rank_vals[ld_ro];
             const int32_t nrank = rank < 0 ? -rank : 1;
             s_nrank[t] = nrank;
             my_ranks = len ? (uint32_t)nrank : 0u;
@@ -505,7 +510,20 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
         last = s_len[np - 1];
         if (staged) {
             if (t < np) s_rec[t] = make_uint4((uint32_t)(s_off[t] - base), (uint32_t)s_len[t], (uint32_t)s_nrank[t], 0u);
-            for (uint64_t k = t; k < run; k += MRPDR_TPB) s_data[k] = data[base + k];
+            // eight loads of a lane in flight at a time (unconditional, clamped to the run's end)
+            for (uint64_t kb = 0; kb < run; kb += 8u * MRPDR_TPB) {
+                T x[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint64_t k = kb + (uint64_t)q * MRPDR_TPB + t;
+                    x[q] = data[base + (k < run ? k : run - 1)];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint64_t k = kb + (uint64_t)q * MRPDR_TPB + t;
+                    if (k < run) s_data[k] = x[q];
+                }
+            }
             __syncthreads();
             // branch-free so that the LDS reads of several packets are in flight together; the
             // fold itself stays in packet order
