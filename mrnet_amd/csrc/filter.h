@@ -481,6 +481,23 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
         const uint64_t pi = p0 + (t < np ? t : np - 1);
         const uint64_t ld_len = in.data_counts[pi], ld_off = in.data_offs[pi];
         const uint64_t ld_rc = in.rank_counts[pi], ld_ro = in.rank_offs[pi];
+        // where the tile's data lies in the column, read by every lane itself (three loads of one
+        // address each): whether the tile is staged is known without a trip through LDS, and
+        // the data loads go out together with the rank load
+        const uint64_t base = in.data_offs[p0], tail_off = in.data_offs[p0 + np - 1];
+        last = in.data_counts[p0 + np - 1];
+        const uint64_t run = tail_off + last - base;
+        // staged only by the workgroup of the first 256 elements: longer arrays read the column
+        // with full wavefronts anyway
+        const bool staged = gridDim.x == 1 && tail_off >= base && run <= PERF_STAGE_ELEMS;
+        T x[8];
+        if (staged && run) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const uint64_t k = (uint64_t)q * MRPDR_TPB + t;
+                x[q] = data[base + (k < run ? k : run - 1)];
+            }
+        }
         if (t < np) {
             const uint64_t len = ld_len;
             s_len[t] = len;
@@ -502,17 +519,17 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
             atomicAdd(&s_total, my_ranks);
             atomicMax(&s_longest, (unsigned long long)my_len);
         }
-        __syncthreads();
-        const uint64_t base = s_off[0], run = s_off[np - 1] + s_len[np - 1] - base;
-        // staged only by the workgroup of the first 256 elements: longer arrays read the column
-        // with full wavefronts anyway
-        const bool staged = gridDim.x == 1 && s_off[np - 1] >= base && run <= PERF_STAGE_ELEMS;
-        last = s_len[np - 1];
         if (staged) {
             if (t < np) s_rec[t] = make_uint4((uint32_t)(s_off[t] - base), (uint32_t)s_len[t], (uint32_t)s_nrank[t], 0u);
-            // eight loads of a lane in flight at a time (unconditional, clamped to the run's end)
-            for (uint64_t kb = 0; kb < run; kb += 8u * MRPDR_TPB) {
-                T x[8];
+            if (run) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint64_t k = (uint64_t)q * MRPDR_TPB + t;
+                    if (k < run) s_data[k] = x[q];
+                }
+            }
+            // what lies beyond the first eight loads of a lane, eight at a time again
+            for (uint64_t kb = 8u * MRPDR_TPB; kb < run; kb += 8u * MRPDR_TPB) {
 #pragma unroll
                 for (int q = 0; q < 8; q++) {
                     const uint64_t k = kb + (uint64_t)q * MRPDR_TPB + t;
@@ -531,11 +548,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
             for (uint32_t j = 0; j < np; j++) {
                 const uint4 r = s_rec[j];
                 const bool active = t < r.y;
-                const T x = s_data[active ? r.x + t : 0u];
-                const T f = perf_fold<OP, T>(acc, x, (int32_t)r.z);
+                const T xv = s_data[active ? r.x + t : 0u];
+                const T f = perf_fold<OP, T>(acc, xv, (int32_t)r.z);
                 acc = active ? f : acc;
             }
         } else {
+            __syncthreads();
 #pragma unroll 4
             for (uint32_t j = 0; j < np; j++) {
                 const uint64_t len = s_len[j];
