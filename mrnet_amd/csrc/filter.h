@@ -22,6 +22,24 @@
 #define FILTER_TILE (MRPDR_TPB * FILTER_LEAF)           // packets per workgroup
 #define FLAT_TILE 2048                                  // packets staged in LDS per step
 
+// Operators the library uses on its own to compute ONE reference filter call (the flat shape)
+// level by level where that gives the same bits as the serial fold:
+//   OP_AVGSUM  integer AVG: the sums of value*count (wrap-around, in T) and of the counts do not
+//              depend on the order; the one division (src/FilterDefinitions.C:561) is done at the top
+//   OP_MINR /  float MIN / MAX: the comparison keeps the new element whenever it is false, so a NaN
+//   OP_MAXR    replaces the result and the element after it replaces the NaN -- a NaN restarts the
+//              fold.  A node therefore carries "a NaN lies below me" (in cnt): joining two nodes, a
+//              right child with the flag wins outright; otherwise the comparison decides, ties going
+//              to the right child as they go to the later packet in the serial fold.
+#define OP_AVGSUM 16
+#define OP_MINR   17
+#define OP_MAXR   18
+
+template <int OP> struct OpTraits {
+    static constexpr bool counted = OP == MRPDR_AVG || OP == OP_AVGSUM || OP == OP_MINR || OP == OP_MAXR;   // cnt travels with the node
+    static constexpr bool pair_result = OP == MRPDR_AVG || OP == OP_AVGSUM;                                   // output packet is (value, count)
+};
+
 struct Partial {            // one node of the tree, as stored between launches
     uint64_t bits;          // value, low bytes
     int32_t  cnt;           // AVG: summed count
@@ -79,6 +97,15 @@ template <int OP, typename T> struct Folder {
             res = or_bits<false>(res, x);
         } else if (OP == MRPDR_AND) {
             res = any ? or_bits<true>(res, x) : x;
+        } else if (OP == OP_AVGSUM) {
+            res = (T)(res + x);             // x is a product already, or a node's sum of products
+            cnt += c;
+        } else if (OP == OP_MAXR) {
+            res = (any && !c) ? ((res > x) ? res : x) : x;
+            cnt |= c;
+        } else if (OP == OP_MINR) {
+            res = (any && !c) ? ((res < x) ? res : x) : x;
+            cnt |= c;
         } else {
             res = (T)(res + mul_cnt<T>(x, c));
             cnt += c;
@@ -93,7 +120,18 @@ template <int OP, typename T> struct Folder {
         else if (OP == MRPDR_MIN) res = (res < x) ? res : x;
         else if (OP == MRPDR_OR) res = or_bits<false>(res, x);
         else if (OP == MRPDR_AND) res = or_bits<true>(res, x);
+        else if (OP == OP_AVGSUM) { res = (T)(res + x); cnt += c; }
+        else if (OP == OP_MAXR) { res = c ? x : ((res > x) ? res : x); cnt |= c; }
+        else if (OP == OP_MINR) { res = c ? x : ((res < x) ? res : x); cnt |= c; }
         else { res = (T)(res + mul_cnt<T>(x, c)); cnt += c; }
+    }
+    // the one division of the flat integer AVG, at the top of its tree
+    __device__ inline bool finish_top()
+    {
+        if (OP != OP_AVGSUM) return finish();
+        if (!any || cnt == 0) return false;
+        res = div_cnt<T>(res, cnt);
+        return true;
     }
     // false: the node is absent (no child, or an AVG whose counts sum to zero)
     __device__ inline bool finish()
@@ -150,7 +188,7 @@ __device__ inline void write_result(uint8_t *result, int32_t *result_ok, bool pr
     for (int b = 0; b < 16; b++) result[b] = 0;
     if (present) {
         st_u<T>(result, v);
-        if (OP == MRPDR_AVG) st_u<int32_t>(result + sizeof(T), cnt);
+        if (OpTraits<OP>::pair_result) st_u<int32_t>(result + sizeof(T), cnt);
     }
     if (result_ok) *result_ok = present ? 1 : 0;
 }
@@ -168,7 +206,7 @@ __device__ inline Partial tile_node(const T *vals, const int32_t *cnts, int nval
     fo.init();
 #pragma unroll
     for (int k = 0; k < FILTER_LEAF; k++)
-        if (k < nvalid) fo.add(vals[k], OP == MRPDR_AVG ? cnts[k] : 1);
+        if (k < nvalid) fo.add(vals[k], OpTraits<OP>::counted ? cnts[k] : 1);
     bool present = fo.finish();
     T v = fo.res;
     int32_t cnt = fo.cnt;
@@ -259,7 +297,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Par
     __shared__ Partial wave_part[MRPDR_TPB / 64];
     T vals[FILTER_LEAF];
     int32_t cnts[FILTER_LEAF];
-    const int nvalid = tile_load<T, OP == MRPDR_AVG>(in, vals, cnts);
+    const int nvalid = tile_load<T, OP == MRPDR_AVG || OP == OP_AVGSUM>(in, vals, cnts);
+    if (OP == OP_AVGSUM) {
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) vals[k] = mul_cnt<T>(vals[k], cnts[k]);
+    } else if (OP == OP_MINR || OP == OP_MAXR) {
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) cnts[k] = vals[k] != vals[k];
+    }
     const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
     if (threadIdx.x == 0) partials[blockIdx.x] = out;
 }
@@ -316,7 +361,7 @@ __device__ inline void tree_top(const Partial *partials, uint64_t np, uint8_t *r
         if (threadIdx.x == 0) fold_nodes<OP, T>(g, stage, m, dense);
     }
     if (threadIdx.x == 0) {
-        const bool present = g.finish();
+        const bool present = g.finish_top();
         write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
     }
 }
@@ -383,27 +428,136 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_stats_top(const Partial *p
 }
 
 // ---- flat shape: one left fold over the whole wave ------------------------------
+// Only what depends on the order runs here: SUM and AVG of float and double (every other flat
+// result is computed level by level, see OP_AVGSUM / OP_MINR / OP_MAXR and the host side).
+// The fold is one dependent chain of additions, a few clocks each -- that chain is the floor;
+// everything around it is kept off it: the whole workgroup loads the next tile (byte order,
+// value * count for AVG) into registers while wavefront 0 adds up the current one out of LDS,
+// sixteen values per batch of 128-bit LDS reads issued one batch ahead; the AVG count is an
+// integer sum and is taken in parallel.
+template <typename T> __device__ inline void lds_read16(T (&v)[16], const T *s)
+{
+    struct alignas(16) Q { T x[16 / sizeof(T)]; };
+    constexpr int PERQ = 16 / sizeof(T);
+#pragma unroll
+    for (int q = 0; q < 16 / PERQ; q++) {
+        const Q a = *reinterpret_cast<const Q *>(s + q * PERQ);
+#pragma unroll
+        for (int k = 0; k < PERQ; k++) v[q * PERQ + k] = a.x[k];
+    }
+}
+
+// A tile's packets as loaded: raw bits, put in order only when they are stored to LDS, so that
+// nothing waits for the loads before the fold of the tile in front has run.  The loads are
+// unconditional (a lane past the end re-reads the last packet).
+template <typename T, bool COUNTS> struct FlatRaw {
+    typedef typename UIntOf<sizeof(T)>::type U;
+    static constexpr int PER = FLAT_TILE / MRPDR_TPB;
+    U raw[PER];
+    uint32_t rawc[PER];
+    uint8_t ord[PER];
+    __device__ inline void issue(const FilterIn &in, uint64_t base)
+    {
+        const uint64_t last = in.n - 1;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            uint64_t i = base + (uint64_t)k * MRPDR_TPB + threadIdx.x;
+            i = i < last ? i : last;
+            raw[k] = ld_u<U>(in.values + i * in.value_stride);
+            rawc[k] = COUNTS ? ld_u<uint32_t>(in.counts + i * in.count_stride) : 1u;
+        }
+        if (in.orders) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const uint64_t i = base + (uint64_t)k * MRPDR_TPB + threadIdx.x;
+                ord[k] = in.orders[i < last ? i : last];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; k++) ord[k] = (uint8_t)(in.swap != 0);
+        }
+    }
+    // values (times count with COUNTS) to dst[FLAT_TILE]; returns the sum of this lane's counts
+    __device__ inline int32_t commit(const FilterIn &in, uint64_t base, T *dst) const
+    {
+        int32_t cnt = 0;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint64_t i = base + (uint64_t)k * MRPDR_TPB + threadIdx.x;
+            U r = raw[k];
+            uint32_t c = rawc[k];
+            if (ord[k]) { r = bswap_u(r); c = bswap_u(c); }
+            T v = from_bits<T>((uint64_t)r);
+            if (COUNTS) v = mul_cnt<T>(v, (int32_t)c);
+            if (i < in.n) { if (COUNTS) cnt += (int32_t)c; } else v = (T)0;
+            dst[k * MRPDR_TPB + threadIdx.x] = v;
+        }
+        return cnt;
+    }
+};
+
 template <int OP, typename T>
 __global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t *result, int32_t *result_ok)
 {
-    __shared__ T       sv[FLAT_TILE];
-    __shared__ int32_t sc[FLAT_TILE];
-    Folder<OP, T> g;
-    g.init();
-    for (uint64_t base = 0; base < in.n; base += FLAT_TILE) {
+    __shared__ __align__(16) T sv[2][FLAT_TILE];
+    __shared__ int32_t s_cnt;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_cnt = 0;
+    const uint64_t ntiles = (in.n + FLAT_TILE - 1) / FLAT_TILE;
+    T acc = (T)0;
+    int32_t mycnt = 0;
+    FlatRaw<T, OP == MRPDR_AVG> regs;
+    if (ntiles) {
+        regs.issue(in, 0);
+        mycnt += regs.commit(in, 0, sv[0]);
+    }
+    __syncthreads();
+    for (uint64_t tile = 0; tile < ntiles; tile++) {
+        const uint64_t base = tile * FLAT_TILE;
         const uint32_t m = (uint32_t)((in.n - base) < FLAT_TILE ? (in.n - base) : FLAT_TILE);
-        for (uint32_t k = threadIdx.x; k < m; k += MRPDR_TPB) {
-            sv[k] = load_value<T>(in, base + k);
-            sc[k] = OP == MRPDR_AVG ? load_count(in, base + k) : 1;
+        const bool more = tile + 1 < ntiles;
+        if (more) regs.issue(in, base + FLAT_TILE);
+        if (t < 64) {           // every lane of wavefront 0 adds the same values: the reads are broadcasts
+            const T *s = sv[tile & 1];
+            uint32_t j = 0;
+            // two register sets take turns, each read one batch ahead of its use (a read past the
+            // tile's m values, still inside the buffer, is not used)
+            T a[16], b[16];
+            lds_read16(a, s);
+            for (; j + 32 <= m; j += 32) {
+                lds_read16(b, s + j + 16);
+                __builtin_amdgcn_sched_barrier(0);          // keep the reads in front of the additions they overlap
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc = acc + a[k];
+                lds_read16(a, s + (j + 48 <= FLAT_TILE ? j + 32 : j));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc = acc + b[k];
+            }
+            if (j + 16 <= m) {
+#pragma unroll
+                for (int k = 0; k < 16; k++) acc = acc + a[k];
+                j += 16;
+            }
+            for (; j < m; j++) acc = acc + s[j];
         }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (uint32_t k = 0; k < m; k++) g.add(sv[k], sc[k]);
+        if (more) mycnt += regs.commit(in, base + FLAT_TILE, sv[(tile + 1) & 1]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const bool present = g.finish();
-        write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
+    if (OP == MRPDR_AVG) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) mycnt += __shfl_xor(mycnt, m, 64);
+        if ((t & 63u) == 0) atomicAdd(&s_cnt, mycnt);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const int32_t cnt = s_cnt;
+        bool present = in.n != 0;
+        if (OP == MRPDR_AVG) {
+            if (cnt == 0) present = false;
+            else acc = div_cnt<T>(acc, cnt);
+        }
+        write_result<OP, T>(result, result_ok, present, acc, cnt);
     }
 }
 

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <type_traits>
 
 #include "common.h"
 #include "scan.h"
@@ -995,37 +996,99 @@ extern "C" int32_t mrpdr_message_parse_sizes(mrpdr_ctx *c, const uint8_t *sizes,
 // filters
 // ---------------------------------------------------------------------------
 template <int OP, typename T>
-static int32_t run_filter(mrpdr_ctx *c, int32_t shape, const FilterIn &in, uint8_t *result,
-                          int32_t *result_ok, hipStream_t st)
+static int32_t run_tree(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
 {
-    if (shape == MRPDR_SHAPE_FLAT) {
-        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok);
-        LAUNCHED("k_filter_flat");
-        return 1;
-    }
     const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
     if (tiles) {
-        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, c->partials);
+        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, partials);
         LAUNCHED("k_filter_tree_tile");
     }
-    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(c->partials, tiles, result, result_ok);
+    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(partials, tiles, result, result_ok);
     LAUNCHED("k_filter_tree_top");
     return 1;
 }
 
+// One reference filter call over the whole wave (MRPDR_SHAPE_FLAT).  Only SUM and AVG of float
+// and double depend on the order of the additions and take the serial kernel; every other result
+// is computed level by level with the same bits: integer SUM / MIN / MAX / OR / AND as they are,
+// integer AVG as sums with one division at the top, float MIN / MAX with the NaN rule carried
+// through the levels.
+template <int OP, typename T>
+static int32_t run_flat(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
+{
+    constexpr bool fp = std::is_floating_point<T>::value;
+    if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
+        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok);
+        LAUNCHED("k_filter_flat");
+        return 1;
+    } else if constexpr (fp && OP == MRPDR_MIN) {
+        return run_tree<OP_MINR, T>(partials, in, result, result_ok, st);
+    } else if constexpr (fp && OP == MRPDR_MAX) {
+        return run_tree<OP_MAXR, T>(partials, in, result, result_ok, st);
+    } else if constexpr (!fp && OP == MRPDR_AVG) {
+        return run_tree<OP_AVGSUM, T>(partials, in, result, result_ok, st);
+    } else {
+        return run_tree<OP, T>(partials, in, result, result_ok, st);
+    }
+}
+
+template <int OP, typename T>
+static int32_t run_filter(Partial *partials, int32_t shape, const FilterIn &in, uint8_t *result,
+                          int32_t *result_ok, hipStream_t st)
+{
+    if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(partials, in, result, result_ok, st);
+    return run_tree<OP, T>(partials, in, result, result_ok, st);
+}
+
 template <typename T>
-static int32_t run_filter_op(mrpdr_ctx *c, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
+static int32_t run_filter_op(Partial *partials, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
                              int32_t *result_ok, hipStream_t st)
 {
     switch (op) {
-    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(c, shape, in, result, result_ok, st);
-    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(c, shape, in, result, result_ok, st);
-    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(c, shape, in, result, result_ok, st);
-    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(c, shape, in, result, result_ok, st);
-    case MRPDR_OR:  return run_filter<MRPDR_OR, T>(c, shape, in, result, result_ok, st);
-    case MRPDR_AND: return run_filter<MRPDR_AND, T>(c, shape, in, result, result_ok, st);
+    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(partials, shape, in, result, result_ok, st);
+    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(partials, shape, in, result, result_ok, st);
+    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(partials, shape, in, result, result_ok, st);
+    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(partials, shape, in, result, result_ok, st);
+    case MRPDR_OR:
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_OR, T>(partials, shape, in, result, result_ok, st);
+        break;
+    case MRPDR_AND:
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_AND, T>(partials, shape, in, result, result_ok, st);
+        break;
     }
     return fail("mrpdr_wave_filter: unknown operator %d", op);
+}
+
+// Argument checks and type dispatch shared by the ctx entry points and the one that allocates nothing.
+static int32_t filter_dispatch(Partial *partials, int32_t op, int32_t type, int32_t shape,
+                               const void *values, uint64_t value_stride,
+                               const void *counts, uint64_t count_stride,
+                               uint64_t n, int32_t swap, const uint8_t *orders,
+                               void *result, int32_t *result_ok, void *stream)
+{
+    if (!result) return fail("mrpdr_wave_filter: NULL result");
+    if (n && !values) return fail("mrpdr_wave_filter: NULL values");
+    if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
+    if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
+        return fail("mrpdr_wave_filter: bitwise operators need an integer type");
+    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap, orders };
+    uint8_t *res = (uint8_t *)result;
+    hipStream_t st = (hipStream_t)stream;
+    switch (type) {
+    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_INT16_T:  return run_filter_op<int16_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_INT32_T:  return run_filter_op<int32_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_INT64_T:  return run_filter_op<int64_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_FLOAT_T:  return run_filter_op<float>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_DOUBLE_T: return run_filter_op<double>(partials, op, shape, in, res, result_ok, st);
+    }
+    // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
+    return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
 }
 
 static int32_t wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,
@@ -1036,33 +1099,8 @@ static int32_t wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape
 {
     if (!ctx_ready("mrpdr_wave_filter", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_filter: n exceeds the ctx limit");
-    if (!result) return fail("mrpdr_wave_filter: NULL result");
-    if (n && !values) return fail("mrpdr_wave_filter: NULL values");
-    if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
-    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
-    if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
-        return fail("mrpdr_wave_filter: bitwise operators need an integer type");
-    FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap, orders };
-    uint8_t *res = (uint8_t *)result;
-    hipStream_t st = (hipStream_t)stream;
-    // Integer Sum (wrap-around), Min, Max, OR and AND do not depend on the order of the fold: the
-    // one-call (flat) result is computed level by level, same bits, no serial chain over n packets.
-    if (shape == MRPDR_SHAPE_FLAT && op != MRPDR_AVG && type != MRPDR_FLOAT_T && type != MRPDR_DOUBLE_T)
-        shape = MRPDR_SHAPE_TREE;
-    switch (type) {
-    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_INT16_T:  return run_filter_op<int16_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_INT32_T:  return run_filter_op<int32_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_INT64_T:  return run_filter_op<int64_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_FLOAT_T:  return run_filter_op<float>(c, op, shape, in, res, result_ok, st);
-    case MRPDR_DOUBLE_T: return run_filter_op<double>(c, op, shape, in, res, result_ok, st);
-    }
-    // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
-    return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
+    return filter_dispatch(c->partials, op, type, shape, values, value_stride, counts, count_stride, n, swap, orders,
+                           result, result_ok, stream);
 }
 
 extern "C" int32_t mrpdr_wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape,

@@ -722,10 +722,10 @@ inline int run_tfilter(int op, PacketWave &in, int shape, uint8_t result16[16], 
     if (out_fmt) *out_fmt = in.get_FormatString();
     return ok ? 0 : -1;
 }
-inline int tfilter_Sum(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_SUM, in, shape, r, nullptr); }
-inline int tfilter_Max(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MAX, in, shape, r, nullptr); }
-inline int tfilter_Min(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_MIN, in, shape, r, nullptr); }
-inline int tfilter_Avg(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_TREE) { return run_tfilter(MRPDR_AVG, in, shape, r, nullptr); }
+inline int tfilter_Sum(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_FLAT) { return run_tfilter(MRPDR_SUM, in, shape, r, nullptr); }
+inline int tfilter_Max(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_FLAT) { return run_tfilter(MRPDR_MAX, in, shape, r, nullptr); }
+inline int tfilter_Min(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_FLAT) { return run_tfilter(MRPDR_MIN, in, shape, r, nullptr); }
+inline int tfilter_Avg(PacketWave &in, uint8_t r[16], int shape = MRPDR_SHAPE_FLAT) { return run_tfilter(MRPDR_AVG, in, shape, r, nullptr); }
 
 
 // ---- built-in array filters ------------------------------------------------------------------

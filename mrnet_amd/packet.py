@@ -231,23 +231,23 @@ def _run_filter(op, ipackets, shape):
     return out
 
 
-def tfilter_Sum(ipackets, shape=W.SHAPE_TREE):
+def tfilter_Sum(ipackets, shape=W.SHAPE_FLAT):
     return _run_filter(W.TFILTER_SUM, ipackets, shape)
 
 
-def tfilter_Max(ipackets, shape=W.SHAPE_TREE):
+def tfilter_Max(ipackets, shape=W.SHAPE_FLAT):
     return _run_filter(W.TFILTER_MAX, ipackets, shape)
 
 
-def tfilter_Min(ipackets, shape=W.SHAPE_TREE):
+def tfilter_Min(ipackets, shape=W.SHAPE_FLAT):
     return _run_filter(W.TFILTER_MIN, ipackets, shape)
 
 
-def tfilter_Avg(ipackets, shape=W.SHAPE_TREE):
+def tfilter_Avg(ipackets, shape=W.SHAPE_FLAT):
     return _run_filter(W.TFILTER_AVG, ipackets, shape)
 
 
-def tfilter_IntSum(ipackets, shape=W.SHAPE_TREE):
+def tfilter_IntSum(ipackets, shape=W.SHAPE_FLAT):
     """src/FilterDefinitions.C:71-88 (defined there, not registered): the int sum of '%d' packets."""
     if ipackets.fmt.text != "%d":
         return None
@@ -319,7 +319,7 @@ def tfilter_IntEqClass(ipackets):
     return _from_columns(ipackets, fmt, ipackets.codec.int_eq_class(cols[0], cols[1], cols[2], ipackets.n))
 
 
-def aggr_FieldSums(ipackets, shape=W.SHAPE_TREE):
+def aggr_FieldSums(ipackets, shape=W.SHAPE_FLAT):
     """The user filters of tests/test_DynamicFilters.C:12-58 (aggr_Count on '%d',
     aggr_CountOddsAndEvens on '%d %d') and Examples/IntegerAddition/IntegerAdditionFilter.C:15-35:
     unpack every packet, add each field up in its own C type, emit one packet of the same format.
@@ -356,14 +356,14 @@ aggr_Count = aggr_FieldSums               # tests/test_DynamicFilters.C:12-33
 aggr_CountOddsAndEvens = aggr_FieldSums   # tests/test_DynamicFilters.C:35-58
 
 
-def BitsetOr(ipackets, shape=W.SHAPE_TREE):
+def BitsetOr(ipackets, shape=W.SHAPE_FLAT):
     """Examples/FaultRecovery/FaultRecoveryFilter.C:107-128: one '%uld' packet, the OR of all inputs."""
     if ipackets.fmt.text != "%uld":
         return None
     return _run_filter(W.FILTER_OR, ipackets, shape)
 
 
-def IntegerPercentiles(ipackets, state=None, shape=W.SHAPE_TREE):
+def IntegerPercentiles(ipackets, state=None, shape=W.SHAPE_FLAT):
     """Examples/FaultRecovery/FaultRecoveryFilter.C:29-86 for waves of '%uld %ud %ud' packets
     (bit set, max, min): OR of the bit sets, maximum of the maxima, minimum of the minima, folded
     into the filter state the reference keeps in `void **filter_state`.  `state` is that state as

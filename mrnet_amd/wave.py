@@ -472,7 +472,7 @@ class Codec:
 
     # ---- filters -----------------------------------------------------------------------
     def filter_raw(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,
-                   shape=SHAPE_TREE, result=None, result_ok=None):
+                   shape=SHAPE_FLAT, result=None, result_ok=None):
         if result is None:
             result = self.empty(16, torch.uint8)
         if result_ok is None:
@@ -551,13 +551,13 @@ class Codec:
         _check(r, "mrpdr_wave_int_eq_class")
         return outs
 
-    def filter_columns(self, op, dtype, values, counts=None, shape=SHAPE_TREE):
+    def filter_columns(self, op, dtype, values, counts=None, shape=SHAPE_FLAT):
         """Filter over decoded columns: values = T[n] tensor, counts = int32[n] (AVG)."""
         n = values.numel()
         return self.filter_raw(op, dtype, _ptr(values), values.element_size(),
                                _ptr(counts), 4, n, 0, shape)
 
-    def filter_wire(self, op, fmt, wire, sender_bo=LITTLEENDIAN, shape=SHAPE_TREE):
+    def filter_wire(self, op, fmt, wire, sender_bo=LITTLEENDIAN, shape=SHAPE_FLAT):
         """Fused decode + filter straight on the wire bytes of a packed fixed-format wave
         ('%T' for SUM/MIN/MAX, '%T %d' for AVG, as the built-in filters require)."""
         want = 2 if op == TFILTER_AVG else 1

@@ -167,6 +167,38 @@ static void test_filters_known_answers(WaveContext &wc)
     end_SubTest("tfilter_Avg(captured reference result)", ok);
 }
 
+// The mirrors called without a shape are ONE reference filter call: a single left fold, and for
+// Avg a single division (src/FilterDefinitions.C:517-561), whatever the number of packets.
+static void test_filters_default_shape(WaveContext &wc)
+{
+    const uint64_t nb = 1025;
+    std::vector<int32_t> v(nb), c(nb);
+    std::vector<float> f(nb);
+    int32_t sum = 0, cnt = 0;
+    float fsum = 0.f;
+    for (uint64_t i = 0; i < nb; i++) {
+        v[i] = (int32_t)(i * 2654435761u % 1000) - 300;
+        c[i] = (int32_t)(i % 5) + 1;
+        sum += v[i] * c[i];
+        cnt += c[i];
+        f[i] = (float)((double)(i * 40503u % 2000001) / 1e3 - 1000.0) * (i % 3 ? 1.f : 1e6f);
+        fsum = fsum + f[i];
+    }
+    std::vector<HostColumn> a(2);
+    a[0].set_scalars(v);
+    a[1].set_scalars(c);
+    PacketWave avg(wc, 7, 100, "%d %d", a, nb);
+    uint8_t r[16];
+    int32_t got[2];
+    bool ok = tfilter_Avg(avg, r) == 0 && (memcpy(got, r, 8), got[0] == sum / cnt && got[1] == cnt);
+    std::vector<HostColumn> b(1);
+    b[0].set_scalars(f);
+    PacketWave fw(wc, 7, 100, "%f", b, nb);
+    float fg;
+    ok = ok && tfilter_Sum(fw, r) == 0 && (memcpy(&fg, r, 4), memcmp(&fg, &fsum, 4) == 0);
+    end_SubTest("tfilter_Avg/Sum(default shape = one reference call, 1025 packets)", ok);
+}
+
 static void test_truncated(WaveContext &wc)
 {
     const char *fmt = "%d %ad";
@@ -442,6 +474,7 @@ int main()
             test_sum<float>(wc, "%f", (float)123.450, nb);   test_sum<double>(wc, "%lf", 123.45678, nb);
         }
         test_filters_known_answers(wc);
+        test_filters_default_shape(wc);
         test_truncated(wc);
         test_string_arrays(wc);
         test_builder_reader(wc);

@@ -56,7 +56,7 @@ def test_filter_parity_flat_and_tree(codec, tok, t, dt, opname, op):
         vals = values_for(dt, n, 17 * n + t, op)
         cnt = counts_for(n, n) if op == O.AVG else None
         # flat: exactly one reference filter call over the wave
-        if n <= 4097:
+        if True:
             ref = O.filter_flat(op, t, vals, cnt)
             got = run_gpu(codec, op, t, dt, vals, cnt, W.SHAPE_FLAT)
             assert got is not None and ref is not None
@@ -122,6 +122,35 @@ def test_nan_and_signed_zero_rules(codec):
             ref = O.filter_tree(op, O.FLOAT_T, v, None, W.TREE_FANINS)
             got = run_gpu(codec, op, O.FLOAT_T, np.float32, v, None, W.SHAPE_TREE)
             assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (v, op)
+
+
+@pytest.mark.parametrize("dt,t", [(np.float32, O.FLOAT_T), (np.float64, O.DOUBLE_T)])
+def test_flat_min_max_nan_restarts_across_levels(codec, dt, t):
+    """One reference call keeps the new element whenever the comparison is false, so a NaN
+    replaces the result and is replaced in turn (src/FilterDefinitions.C:2042-2136).  The flat
+    MIN / MAX of float types is computed level by level with that rule carried along: NaNs (with
+    their payload bits) and signed zeros at lane, wavefront, workgroup and launch boundaries."""
+    bits = np.dtype(dt).itemsize * 8
+    udt = np.uint32 if bits == 32 else np.uint64
+    nan_a = np.array([0x7FC00001 if bits == 32 else 0x7FF8000000000001], udt).view(dt)[0]
+    nan_b = np.array([0xFFC12345 if bits == 32 else 0xFFF8000000012345], udt).view(dt)[0]
+    for n in (5, 64, 257, 1024, 1025, 4096, 4100, 70000):
+        base = values_for(dt, n, 31 * n + 7, O.MIN)
+        spots = sorted({0, 1, 3, 4, 63, 64, 255, 256, 1023, 1024, 1025, 2047, 4095, 4096, n // 2, n - 2, n - 1})
+        spots = [p for p in spots if 0 <= p < n]
+        variants = [[p] for p in spots] + [[spots[0], spots[-1]], spots, [n - 1], []]
+        for k, nan_at in enumerate(variants):
+            v = base.copy()
+            for q, p in enumerate(nan_at):
+                v[p] = nan_a if q % 2 == 0 else nan_b
+            if k % 3 == 0:          # ties between +0 and -0 after the last NaN: the later one wins
+                tail = (nan_at[-1] + 1) if nan_at else 0
+                if tail + 2 <= n:
+                    v[tail:] = np.where(np.arange(n - tail) % 2 == 0, dt(0.0), dt(-0.0))
+            for op in (O.MIN, O.MAX):
+                ref = O.filter_flat(op, t, v)
+                got = run_gpu(codec, op, t, dt, v, None, W.SHAPE_FLAT)
+                assert np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), (n, nan_at[:4], op)
 
 
 def test_empty_wave_and_zero_counts(codec):

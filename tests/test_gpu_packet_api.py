@@ -121,6 +121,41 @@ def test_filters_min_max_avg_and_rejections(codec):
     assert tfilter_Avg(PacketWave(codec, 7, 100, "%d %d", [np.ones(2, np.int32), np.zeros(2, np.int32)])) is None
 
 
+@pytest.mark.parametrize("n", [4, 1025, 65536])
+@pytest.mark.parametrize("fmt", ["%d %d", "%hd %d", "%f", "%lf %d", "%uc %d", "%uld %d", "%lf", "%f %d"])
+def test_filter_mirrors_default_to_one_reference_call(codec, fmt, n):
+    """tfilter_Sum / Max / Min / Avg called the way a ported tool calls them -- no shape
+    argument -- return what ONE reference filter call over the wave returns
+    (src/FilterDefinitions.C:101-149, 237-286, 374-424, 517-561): a single left fold, one division
+    for Avg.  Bit for bit, every type, also where the order matters (float Sum, every Avg)."""
+    from wavegen import random_values, splitmix64
+    toks = [t[1:] for t in fmt.split()]
+    dt = np.dtype(TOK_DTYPE[toks[0]])
+    t = int(W.Format("%" + toks[0]).types[0])
+    if dt.kind == "f":
+        u = splitmix64(5 * n + 1, n)
+        vals = (((u % np.uint64(2_000_001)).astype(np.float64) / 1e3 - 1000.0)
+                * np.array([1e-3, 1.0, 1e3, 1e6])[(u >> np.uint64(40)) % np.uint64(4)]).astype(dt)
+    else:
+        vals = random_values(dt, n, 5 * n + 1)
+        if dt.kind == "i":
+            vals = np.where(vals == np.iinfo(dt).min, dt.type(1), vals)
+    if len(toks) == 2:
+        cnts = (splitmix64(n + 3, n) % np.uint64(5) + np.uint64(1)).astype(np.int32)
+        wave = received(codec, PacketWave(codec, 7, 100, fmt, [vals, cnts]))
+        out = tfilter_Avg(wave)
+        ref = O.filter_flat(O.AVG, t, vals, cnts)
+        assert out is not None and out.get_FormatString() == fmt
+        assert out.values(0)[0].tobytes() == np.asarray(ref[0]).tobytes(), (fmt, n)
+        assert int(out.values(1)[0]) == ref[1]
+        return
+    wave = received(codec, PacketWave(codec, 7, 100, fmt, [vals]))
+    for mirror, op in ((tfilter_Sum, O.SUM), (tfilter_Max, O.MAX), (tfilter_Min, O.MIN)):
+        out = mirror(wave)
+        ref = O.filter_flat(op, t, vals)
+        assert out.values(0)[0].tobytes() == np.asarray(ref[0]).tobytes(), (fmt, n, op)
+
+
 def test_receive_side_errors(codec):
     fmt = "%d %ad"
     n = 50
