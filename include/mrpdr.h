@@ -347,6 +347,22 @@ int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_
                                 uint64_t n, const uint8_t *byteorders,
                                 void *result, int32_t *result_ok, void *stream);
 
+/* mrpdr_wave_filter for callers that cannot allocate device memory or create a ctx: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  (No counterpart in the
+ * reference.)  Same arguments and results as mrpdr_wave_filter, bit for bit, minus the ctx: the
+ * nodes the two launches hand over live in a device array built into the library (256 KiB, held by
+ * every GPU the library runs on until the process ends), so the call makes no hipMalloc / hipFree
+ * and needs no workspace.  Limits: n <= 2^24 packets (FALSE beyond); the kernels run on the calling
+ * thread's current device, where all pointers must live; all calls on one GPU share that GPU's
+ * array, so two calls that overlap in time on one GPU (different streams or threads) race --
+ * serialise them.  The first call on a device resolves the array's address
+ * (hipGetSymbolAddress): make one call outside graph capture first. */
+int32_t mrpdr_wave_filter_noalloc(int32_t op, int32_t type, int32_t shape,
+                                  const void *values, uint64_t value_stride,
+                                  const void *counts, uint64_t count_stride,
+                                  uint64_t n, int32_t swap,
+                                  void *result, int32_t *result_ok, void *stream);
+
 /* tfilter_Min, tfilter_Max and tfilter_Avg of one '<T> %d' wave in ONE pass over the packets
  * (a monitoring stream usually carries all three).  Same arguments as mrpdr_wave_filter with the
  * declared tree shape; results = 3 x 16 bytes (MIN, MAX, AVG output packets' data), results_ok = 3

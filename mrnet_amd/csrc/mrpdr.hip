@@ -5,6 +5,7 @@
 #include <string.h>
 #include <stdarg.h>
 #include <type_traits>
+#include <mutex>
 
 #include "common.h"
 #include "scan.h"
@@ -1122,6 +1123,53 @@ extern "C" int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *c, int32_t op, int32_t typ
     if (n && !byteorders) return fail("mrpdr_wave_filter_mixed: NULL byteorders");
     return wave_filter(c, op, type, shape, values, value_stride, counts, count_stride, n, 0, n ? byteorders : nullptr,
                        result, result_ok, stream);
+}
+
+// ---------------------------------------------------------------------------
+// mrpdr_wave_filter without a ctx and without any allocation
+// ---------------------------------------------------------------------------
+// The tree nodes between the two launches live in a file-scope device array instead of a ctx
+// workspace.  Every GPU the library runs on holds its own copy of the array, at its own address,
+// until the process ends; the name below is only the host-side handle of it, the address the
+// kernels get comes from hipGetSymbolAddress, once per device.
+#define NOALLOC_MAX_PACKETS (1ull << 24)
+#define NOALLOC_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[(NOALLOC_MAX_PACKETS / FILTER_TILE + 1) * sizeof(Partial)];
+
+static void *g_scratch_ptr[NOALLOC_MAX_DEVICES];       // per device: where its copy of scratch lives
+static std::mutex g_scratch_lock;
+
+// The current device's copy of scratch (resolved on the first call on that device).
+static int32_t scratch_of_current_device(const char *who, void **out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return fail("%s: no current HIP device", who);
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) return fail("%s: device %d is beyond the %d this library keeps scratch for", who, dev, NOALLOC_MAX_DEVICES);
+    std::lock_guard<std::mutex> hold(g_scratch_lock);
+    if (!g_scratch_ptr[dev]) {
+        void *ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) return fail("%s: hipGetSymbolAddress(scratch): %s", who, hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return 1;
+}
+
+extern "C" int32_t mrpdr_wave_filter_noalloc(int32_t op, int32_t type, int32_t shape,
+                                             const void *values, uint64_t value_stride,
+                                             const void *counts, uint64_t count_stride,
+                                             uint64_t n, int32_t swap,
+                                             void *result, int32_t *result_ok, void *stream)
+{
+    if (n > NOALLOC_MAX_PACKETS)
+        return fail("mrpdr_wave_filter_noalloc: n=%llu exceeds the %llu packets the built-in scratch holds nodes for",
+                    (unsigned long long)n, (unsigned long long)NOALLOC_MAX_PACKETS);
+    void *ptr = nullptr;
+    if (!scratch_of_current_device("mrpdr_wave_filter_noalloc", &ptr)) return 0;
+    // nothing in the array has to start from zero: the first launch writes every node the second reads
+    return filter_dispatch((Partial *)ptr, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
+                           result, result_ok, stream);
 }
 
 template <typename T>
