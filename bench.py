@@ -221,7 +221,20 @@ def cpu_baseline(n, m, reps):
     outv[:, 8:] = vals.view(np.uint8)                         # encode: native order
     t_vec = time.perf_counter() - t0
     assert np.array_equal(outv.reshape(-1), arena)
+    # config 1 beside it: the 4-packet '%d' wave (value 1, as microbench_BE sends it) through the
+    # oracle's per-packet path -- decode four packets, tfilter_Sum, encode the one output packet
+    one = [{"type": O.INT32_T, "values": np.ones(4, np.int32)}]
+    a1, o1, l1 = O.wave_encode("%d", one, 4)
+    reps1 = 2000
+    t0 = time.perf_counter()
+    for _ in range(reps1):
+        d1, ok1 = O.wave_decode("%d", a1, o1, l1, O.LITTLE)
+        s1 = O.filter_flat(O.SUM, O.INT32_T, d1[0]["values"])
+        e1, _, _ = O.wave_encode("%d", [{"type": O.INT32_T, "values": np.array([s1[0]], np.int32)}], 1)
+    c1_us = (time.perf_counter() - t0) / reps1 * 1e6
+    assert int(e1.view(np.int32)[0]) == 4
     return {"value": round(nbytes / best[0] / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "c1_us_per_wave": round(c1_us, 2),
             "sample": "%d packets x '%%af'[%d] (%.0f MiB of data), decode big-endian + sizeof + encode, "
                       "best of %d, decode %.2f s encode %.2f s" % (n, m, data / 2**20, reps, best[1], best[2]),
             "all_cores": {"value": round(nbytes / t_all / 1e9, 3), "unit": "GB/s", "cores": cores,
@@ -244,15 +257,53 @@ def small_wave_extras(codec):
     cols = codec.alloc_columns(fmt, n)
     ok = torch.empty(n, dtype=torch.int32, device=dev)
 
-    def c2():
+    def c2_unfused():
         codec.filter_raw(W.TFILTER_SUM, W.DataType.INT32_T, wire.arena.data_ptr(), 4, None, 4, n, 0,
                          W.SHAPE_TREE, res, rok)
         codec.decode_into(fmt, wire, cols, ok)
         codec.encode_into(fmt, cols, wire)
-    out["c2_us_per_wave"] = round(time_call(c2, 200) * 1e6, 2)
-    tg = time_graph(c2, 200)
+    out["c2_us_per_wave_unfused"] = round(time_call(c2_unfused, 200) * 1e6, 2)
+    # the same work as a node does it wave after wave: decode + Sum in one pass over the rows
+    # (two launches), the re-encode (one launch), the calls bound to their buffers once
+    def bind_c2():          # bound to the stream that is current when this runs
+        dec_sum = codec.bind_decode_filter(fmt, wire, cols, ok, W.TFILTER_SUM, W.SHAPE_FLAT, res, rok)
+        enc = codec.bind_encode(fmt, cols, wire)
+
+        def c2():
+            dec_sum()
+            enc()
+        return c2
+    out["c2_us_per_wave"] = round(time_call(bind_c2(), 200) * 1e6, 2)
+    tg = time_graph(bind_c2, 200)
     out["c2_us_per_wave_hipgraph"] = None if tg is None else round(tg * 1e6, 2)
     assert int(res[:4].view(torch.int32).item()) == int(vals.sum(dtype=torch.int32).item())
+    assert torch.equal(cols[0].values.view(torch.int32), vals) and torch.equal(wire.arena.view(torch.int32), vals)
+    # config 1: the 4-packet '%d' wave of the reference's microbench (tests/microbench_FE.C:61,145,207
+    # over local-1x4.top): decode + Sum; the 16 result bytes are the encoded output packet
+    w1 = W.WireWave(torch.ones(4, dtype=torch.int32, device=dev).view(torch.uint8), 4, None, None, 4)
+    cols1, ok1 = codec.alloc_columns(fmt, 4), torch.empty(4, dtype=torch.int32, device=dev)
+    c1 = codec.bind_decode_filter(fmt, w1, cols1, ok1, W.TFILTER_SUM, W.SHAPE_FLAT, res, rok)
+    out["c1_us_per_wave"] = round(time_call(c1, 500) * 1e6, 2)
+
+    def c1_latency():
+        c1()
+        torch.cuda.synchronize()
+    out["c1_us_per_wave_host_waits"] = round(time_call(c1_latency, 500) * 1e6, 2)
+    assert int(res[:4].view(torch.int32).item()) == 4
+    # what ONE reference filter call (the flat shape, the mirrors' default) costs where the order of
+    # the additions matters -- a serial chain -- beside the declared tree; 65,536 packets each
+    vf = torch.randn(n, dtype=torch.float32, device=dev)
+    rows64 = torch.empty((n, 12), dtype=torch.uint8, device=dev)
+    rows64[:, :8] = (torch.randn(n, dtype=torch.float64, device=dev) * 1e-4 + 1e-3).view(torch.uint8).view(n, 8)
+    rows64[:, 8:] = torch.ones(n, dtype=torch.int32, device=dev).view(torch.uint8).view(n, 4)
+    p64 = rows64.data_ptr()
+    for name, shape in (("flat", W.SHAPE_FLAT), ("tree", W.SHAPE_TREE)):
+        f_sum = codec.bind_filter(W.TFILTER_SUM, W.DataType.FLOAT_T, vf.data_ptr(), 4, None, 0, n, 0, shape, res, rok)
+        f_avg = codec.bind_filter(W.TFILTER_AVG, W.DataType.DOUBLE_T, p64, 12, p64 + 8, 12, n, 0, shape, res, rok)
+        i_avg = codec.bind_filter(W.TFILTER_AVG, W.DataType.INT32_T, p64, 12, p64 + 8, 12, n, 0, shape, res, rok)
+        out["%s_sum_f32_64k_us" % name] = round(time_call(f_sum, 50) * 1e6, 1)
+        out["%s_avg_f64_64k_us" % name] = round(time_call(f_avg, 50) * 1e6, 1)
+        out["%s_avg_i32_64k_us" % name] = round(time_call(i_avg, 50) * 1e6, 1)
     # config 5 shape: '%lf %d', fused Min / Max / Avg on the wire (one GPU's 131,072-packet shard)
     n5 = 131072
     fmt5 = W.Format("%lf %d")
@@ -426,15 +477,15 @@ def time_call(fn, reps):
     return (time.perf_counter() - t0) / reps
 
 
-def time_graph(fn, reps):
-    """The same calls captured once in a HIP graph and replayed: what the wave costs on the GPU
-    when the host does not pay a library call per launch (measured: the same time, these waves
-    are bound by the dependent launches on the device, not by the host).  None when capture
-    is refused."""
+def time_graph(make_fn, reps):
+    """The calls of make_fn() (made on the capturing stream) captured once in a HIP graph and
+    replayed: what the wave costs on the GPU when the host does not pay a library call per
+    launch.  None when capture is refused."""
     try:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
+            fn = make_fn()
             fn()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=side):
@@ -543,8 +594,42 @@ def end_to_end_pipelined(codec, n, m, slices=16, nbuf=3, reps=5):
     return ((data + payload) + (payload + data + 8 * (n + 1))) / best / 1e9, best
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes of this same
+    command (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would), hand
+    rank 0's output through and return the worst exit code.  Runs before this process has touched
+    the GPU in any way, and the ranks are children, never a replacement of this process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                  # a rank that is gone leaves the others in a barrier
+                    q.terminate()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -612,11 +697,15 @@ def main():
         plain_ms = codec.plain_copy_ms(st.dst.arena[:a.packets * a.elems * 4], st.cols[0].values, 20)
         plain = st.bytes_copy_kernel / (plain_ms * 1e-3) / 1e9
         achieved = st.bytes_copy_kernel / (dec_ms * 1e-3) / 1e9
-        traffic = None
+        # HBM bytes per launch from the PMC counters: not collected by this run (counters need
+        # rocprofv3 passes of their own); the figure of the committed counter run of this same
+        # command is carried along and labelled as such
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath) and (a.packets, a.elems) == (4096, 65536):
             try:
                 traffic = json.load(open(tpath)).get("k_copy_decode_swap4_hbm_bytes_per_launch")
+                traffic_source = "profiles/traffic.json (rocprofv3 --pmc passes of this command, not this run)"
             except Exception:
                 traffic = None
         out = {
@@ -634,6 +723,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_copy<4,swap,decode>",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "bytes_per_launch": st.bytes_copy_kernel,
                          "avg_launch_ms": round(dec_ms, 4),
                          "encode_kernel": {"kernel": "k_copy<4,noswap,encode>", "avg_launch_ms": round(enc_ms, 4),

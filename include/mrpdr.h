@@ -347,6 +347,19 @@ int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_
                                 uint64_t n, const uint8_t *byteorders,
                                 void *result, int32_t *result_ok, void *stream);
 
+/* What a tree node does with an upstream wave, in one call: decode the packets
+ * (Packet::decode_pdr_data, src/Packet.C:106-133, triggered by the filter's (*pkt)[0],
+ * src/FilterDefinitions.C:148) AND fold their first field with tfilter_Sum / Min / Max / Avg
+ * (src/FilterDefinitions.C:90-645).  f must be a format of scalars only; the filtered value is
+ * field 0 (AVG: field 1 is its int32 count); cols / ok as for mrpdr_wave_decode, result /
+ * result_ok as for mrpdr_wave_filter over the decoded column -- the same bits.  For a packed arena
+ * (offsets NULL, stride <= 32) every row is read once and the call is two launches; other
+ * layouts, and the flat SUM / AVG of float and double (a serial fold), run decode and filter one
+ * after the other inside the call. */
+int32_t mrpdr_wave_decode_filter(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr_wire *wire, uint64_t n,
+                                 int32_t sender_byteorder, mrpdr_column *cols, int32_t *ok,
+                                 int32_t op, int32_t shape, void *result, int32_t *result_ok, void *stream);
+
 /* mrpdr_wave_filter for callers that cannot allocate device memory or create a ctx: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  (No counterpart in the
  * reference.)  Same arguments and results as mrpdr_wave_filter, bit for bit, minus the ctx: the

@@ -17,6 +17,7 @@
 #include "strarr.h"
 #include "tile.h"
 #include "eqclass.h"
+#include "fused.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1123,6 +1124,94 @@ extern "C" int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *c, int32_t op, int32_t typ
     if (n && !byteorders) return fail("mrpdr_wave_filter_mixed: NULL byteorders");
     return wave_filter(c, op, type, shape, values, value_stride, counts, count_stride, n, 0, n ? byteorders : nullptr,
                        result, result_ok, stream);
+}
+
+// ---------------------------------------------------------------------------
+// decode + filter in one pass over the rows (packed scalar-only waves)
+// ---------------------------------------------------------------------------
+// The operator the tree kernels run for (op, shape) on T, or -1 when the result needs the serial
+// kernel (one reference call of SUM / AVG over float or double).
+static int tree_op_for(int32_t op, int32_t shape, bool fp)
+{
+    if (shape == MRPDR_SHAPE_TREE) return op;
+    if (fp) return (op == MRPDR_SUM || op == MRPDR_AVG) ? -1 : op == MRPDR_MIN ? OP_MINR : op == MRPDR_MAX ? OP_MAXR : op;
+    return op == MRPDR_AVG ? OP_AVGSUM : op;
+}
+
+template <int OP, typename T>
+static int32_t launch_fused(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, uint64_t n,
+                            int32_t swap, int32_t *ok, uint8_t *result, int32_t *result_ok, hipStream_t st)
+{
+    const uint32_t tiles = blocks_for(n, FILTER_TILE);
+    k_rows_decode_filter<OP, T><<<tiles, MRPDR_TPB, FILTER_TILE * wd.stride, st>>>(f->dev, wd, cd, n, swap, ok, c->partials);
+    LAUNCHED("k_rows_decode_filter");
+    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(c->partials, tiles, result, result_ok);
+    LAUNCHED("k_filter_tree_top");
+    return 1;
+}
+
+template <typename T>
+static int32_t launch_fused_op(int top, mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, uint64_t n,
+                               int32_t swap, int32_t *ok, uint8_t *result, int32_t *result_ok, hipStream_t st)
+{
+    constexpr bool fp = std::is_floating_point<T>::value;
+    switch (top) {
+    case MRPDR_SUM: return launch_fused<MRPDR_SUM, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st);
+    case MRPDR_MIN: return launch_fused<MRPDR_MIN, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st);
+    case MRPDR_MAX: return launch_fused<MRPDR_MAX, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st);
+    case MRPDR_AVG: return launch_fused<MRPDR_AVG, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st);
+    case MRPDR_OR:  if constexpr (!fp) return launch_fused<MRPDR_OR, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st); break;
+    case MRPDR_AND: if constexpr (!fp) return launch_fused<MRPDR_AND, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st); break;
+    case OP_AVGSUM: if constexpr (!fp) return launch_fused<OP_AVGSUM, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st); break;
+    case OP_MINR:   if constexpr (fp) return launch_fused<OP_MINR, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st); break;
+    case OP_MAXR:   if constexpr (fp) return launch_fused<OP_MAXR, T>(c, f, wd, cd, n, swap, ok, result, result_ok, st); break;
+    }
+    return fail("mrpdr_wave_decode_filter: unknown operator");
+}
+
+extern "C" int32_t mrpdr_wave_decode_filter(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire, uint64_t n,
+                                            int32_t sender_bo, mrpdr_column *cols, int32_t *ok,
+                                            int32_t op, int32_t shape, void *result, int32_t *result_ok, void *stream)
+{
+    const char *who = "mrpdr_wave_decode_filter";
+    if (!check_common(who, c, f, n)) return 0;
+    if (sender_bo != MRPDR_LITTLEENDIAN && sender_bo != MRPDR_BIGENDIAN) return fail("%s: bad byte order %d", who, sender_bo);
+    if (!f->fixed || f->dev.nf < 1) return fail("%s: needs a format of scalars only, the filtered value first", who);
+    if (op < MRPDR_SUM || op > MRPDR_AND) return fail("%s: unknown operator %d", who, op);
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("%s: unknown shape %d", who, shape);
+    if (op == MRPDR_AVG && (f->dev.nf < 2 || f->dev.f[1].type != MRPDR_INT32_T))
+        return fail("%s: AVG needs the int32 count as second field", who);
+    if (!result) return fail("%s: NULL result", who);
+    const int32_t type = f->dev.f[0].type;
+    const bool fp = type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T;
+    if ((op == MRPDR_OR || op == MRPDR_AND) && fp) return fail("%s: bitwise operators need an integer type", who);
+    ColsDev cd;
+    WireDev wd;
+    if (!fill_cols(who, f, cols, n, false, &cd, false)) return 0;
+    if (!fill_wire(who, f, wire, n, &wd)) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int top = tree_op_for(op, shape, fp);
+    const int32_t swap = sender_bo != MRPDR_LITTLEENDIAN;
+    if (n == 0 || top < 0 || !rows_path_ok(f, wd) || wd.stride > FUSED_MAX_STRIDE) {
+        // what the one pass cannot do: decode, then the filter over the decoded columns
+        if (!decode_begin(who, c, f, wire, n, sender_bo, nullptr, cols, ok, nullptr, stream)) return 0;
+        return filter_dispatch(c->partials, op, type, shape, n ? cols[0].values : nullptr, f->dev.f[0].width,
+                               (n && op == MRPDR_AVG) ? cols[1].values : nullptr, 4, n, 0, nullptr, result, result_ok, stream);
+    }
+    uint8_t *res = (uint8_t *)result;
+    switch (type) {
+    case MRPDR_CHAR_T:   return launch_fused_op<int8_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_UCHAR_T:  return launch_fused_op<uint8_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_INT16_T:  return launch_fused_op<int16_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_UINT16_T: return launch_fused_op<uint16_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_INT32_T:  return launch_fused_op<int32_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_UINT32_T: return launch_fused_op<uint32_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_INT64_T:  return launch_fused_op<int64_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_UINT64_T: return launch_fused_op<uint64_t>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_FLOAT_T:  return launch_fused_op<float>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    case MRPDR_DOUBLE_T: return launch_fused_op<double>(top, c, f, wd, cd, n, swap, ok, res, result_ok, st);
+    }
+    return fail("%s: type %d is not a scalar the filters accept", who, type);
 }
 
 // ---------------------------------------------------------------------------

@@ -346,6 +346,49 @@ class Codec:
         _check(fn(self.handle, fmt.handle, C.byref(w), wire.n, bo, _c_columns(cols), _ptr(ok), _stream()),
                "mrpdr_wave_decode")
 
+    def decode_filter_into(self, fmt, wire, cols, ok, op, shape=SHAPE_FLAT, sender_bo=LITTLEENDIAN,
+                           result=None, result_ok=None):
+        """Decode a scalar-only wave and fold its first field in one call (a tree node's work on
+        an upstream wave): columns and ok as decode_into, (result, result_ok) as filter_columns."""
+        result = self.empty(16, torch.uint8) if result is None else result
+        result_ok = self.empty(1, torch.int32) if result_ok is None else result_ok
+        w = wire.c_struct()
+        _check(self._lib.mrpdr_wave_decode_filter(self.handle, fmt.handle, C.byref(w), wire.n, sender_bo,
+                                                  _c_columns(cols), _ptr(ok), op, shape, _ptr(result),
+                                                  _ptr(result_ok), _stream()), "mrpdr_wave_decode_filter")
+        return result, result_ok
+
+    # ---- calls bound once -------------------------------------------------------------------
+    # A node that handles wave after wave of one stream calls the same entry points with the same
+    # buffers every time.  bind_* converts the arguments to their C form once (structs, pointers,
+    # the current HIP stream) and returns a function that only makes the call.
+    def _bound(self, name, *args):
+        fn = getattr(self._lib, name)
+
+        def call():
+            if not fn(*args):
+                raise PdrError("%s: %s" % (name, capi.last_error()))
+        call.keep = args                  # the ctypes structures must outlive the closure's calls
+        return call
+
+    def bind_decode(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN):
+        return self._bound("mrpdr_wave_decode", self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
+                           sender_bo, _c_columns(cols), _ptr(ok), _stream())
+
+    def bind_encode(self, fmt, cols, wire):
+        return self._bound("mrpdr_wave_encode", self.handle, fmt.handle, _c_columns(cols), wire.n,
+                           C.byref(wire.c_struct()), _stream())
+
+    def bind_decode_filter(self, fmt, wire, cols, ok, op, shape, result, result_ok, sender_bo=LITTLEENDIAN):
+        return self._bound("mrpdr_wave_decode_filter", self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
+                           sender_bo, _c_columns(cols), _ptr(ok), op, shape, _ptr(result), _ptr(result_ok),
+                           _stream())
+
+    def bind_filter(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap, shape,
+                    result, result_ok):
+        return self._bound("mrpdr_wave_filter", self.handle, op, int(dtype), shape, values_ptr, value_stride,
+                           counts_ptr, count_stride, n, swap, _ptr(result), _ptr(result_ok), _stream())
+
     def decode(self, fmt, wire, sender_bo=LITTLEENDIAN):
         """Decode a wave; returns (columns, ok).  Array columns are allocated from the
         totals the walk reports, so this synchronises once for variable formats."""

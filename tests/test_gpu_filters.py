@@ -200,6 +200,90 @@ def test_fused_decode_filter_on_the_wire(codec, shape):
         assert res.cpu().numpy()[:12].tobytes() == out_arena.tobytes()
 
 
+@pytest.mark.parametrize("tok,t,dt", TYPES)
+def test_decode_and_filter_in_one_call(codec, tok, t, dt):
+    """mrpdr_wave_decode_filter = decode_pdr_data of every packet + the filter's fold of (*pkt)[0]
+    (src/FilterDefinitions.C:148): columns and ok as the decode alone writes them, the result as the
+    filter over the decoded column gives it -- against the oracle, every operator, both shapes, both
+    sender byte orders, packed rows with and without padding, formats with further fields."""
+    dt = np.dtype(dt)
+    for fmt_s, n in (("%" + tok, 4), ("%" + tok, 1025), ("%" + tok + " %d", 5000), ("%" + tok + " %d %uc %lf", 2049),
+                     ("%" + tok + " %d", 65536)):
+        fmt = W.Format(fmt_s)
+        vals = values_for(dt, n, 3 * n + t, O.AVG)
+        host = [vals]
+        if len(fmt) > 1:
+            host.append(counts_for(n, n + 1))
+        if len(fmt) > 2:
+            host += [random_values(np.uint8, n, 7), random_values(np.float64, n, 8)]
+        ocols = [{"type": int(ty), "values": v} for ty, v in zip(fmt.types, host)]
+        arena, _, _ = O.wave_encode(fmt_s, ocols, n)
+        fixed = fmt.fixed_bytes
+        for bo, stride in ((W.LITTLEENDIAN, fixed), (W.BIGENDIAN, fixed), (W.BIGENDIAN, (fixed + 15) // 16 * 16),
+                           (W.LITTLEENDIAN, 48)):            # 48 > 32: the two-step path inside the call
+            rows = np.full((n, stride), 0xEE, np.uint8)
+            src = arena.reshape(n, fixed)
+            at = 0
+            for w in fmt.widths:
+                rows[:, at:at + w] = src[:, at:at + w][:, ::-1] if bo == W.BIGENDIAN else src[:, at:at + w]
+                at += w
+            wire = W.WireWave(codec.to_device(rows.reshape(-1)), n, None, None, stride)
+            for op in (O.SUM, O.MIN, O.MAX, O.AVG):
+                if op == O.AVG and len(fmt) < 2:
+                    continue
+                for shape in (W.SHAPE_FLAT, W.SHAPE_TREE):
+                    cols = codec.alloc_columns(fmt, n)
+                    ok = codec.empty(n, torch.int32)
+                    res, rok = codec.decode_filter_into(fmt, wire, cols, ok, op, shape, bo)
+                    torch.cuda.synchronize()
+                    assert bool(ok.all())
+                    for f, v in enumerate(host):
+                        assert W.Codec.to_numpy(cols[f].values).view(v.dtype).tobytes() == v.tobytes(), (fmt_s, f)
+                    cnt = host[1] if op == O.AVG else None
+                    ref = (O.filter_flat(op, t, vals, cnt) if shape == W.SHAPE_FLAT
+                           else O.filter_tree(op, t, vals, cnt, W.TREE_FANINS))
+                    got = W.result_value(res, rok, dt, op)
+                    assert got is not None and np.asarray(got[0]).tobytes() == np.asarray(ref[0]).tobytes(), \
+                        (fmt_s, n, bo, stride, op, shape)
+                    if op == O.AVG:
+                        assert got[1] == ref[1]
+
+
+def test_decode_and_filter_refusals_and_short_packets(codec):
+    fmt = W.Format("%d %d")
+    n = 3000
+    v, c = random_values(np.int32, n, 1), counts_for(n, 2)
+    rows = np.concatenate([v.view(np.uint8).reshape(n, 4), c.view(np.uint8).reshape(n, 4)], axis=1)
+    wire = W.WireWave(codec.to_device(rows.reshape(-1)), n, None, None, 8)
+    cols, ok = codec.alloc_columns(fmt, n), codec.empty(n, torch.int32)
+    with pytest.raises(W.PdrError):
+        codec.decode_filter_into(W.Format("%d %as"), wire, cols, ok, O.SUM)          # not scalars only
+    with pytest.raises(W.PdrError):
+        codec.decode_filter_into(W.Format("%d %f"), wire, cols, ok, O.AVG)           # count is not '%d'
+    with pytest.raises(W.PdrError):
+        codec.decode_filter_into(W.Format("%f"), wire, cols, ok, W.FILTER_OR)        # bitwise on float
+    with pytest.raises(W.PdrError):
+        codec.decode_filter_into(fmt, wire, cols, ok, 17)
+    # packets shorter than the format: ok = 0, the missing fields read as zero, in the columns
+    # and in the fold alike (as the decode followed by the filter over the columns)
+    lens = np.full(n, 8, np.uint64)
+    lens[5::7] = 4
+    lens[11::13] = 3
+    short = W.WireWave(wire.arena, n, None, codec.to_device(lens), 8)
+    res, rok = codec.decode_filter_into(fmt, short, cols, ok, O.AVG, W.SHAPE_FLAT)
+    torch.cuda.synchronize()
+    dv = np.where(lens >= 4, v, 0).astype(np.int32)
+    dc = np.where(lens >= 8, c, 0).astype(np.int32)
+    assert np.array_equal(W.Codec.to_numpy(ok), (lens >= 8).astype(np.int32))
+    assert np.array_equal(W.Codec.to_numpy(cols[0].values), dv) and np.array_equal(W.Codec.to_numpy(cols[1].values), dc)
+    ref = O.filter_flat(O.AVG, O.INT32_T, dv, dc)
+    got = W.result_value(res, rok, np.dtype(np.int32), O.AVG)
+    assert (int(got[0]), got[1]) == (int(ref[0]), ref[1])
+    # an empty wave: nothing decoded, no output packet
+    res, rok = codec.decode_filter_into(fmt, W.WireWave(wire.arena, 0, None, None, 8), cols, ok, O.SUM)
+    assert int(rok.item()) == 0
+
+
 @pytest.mark.parametrize("opname,op", OPS)
 def test_sharded_wave_combine(codec, opname, op):
     """A 1M-packet '%lf %d' wave in 8 packet ranges (one per GPU of a node): per-range tree
