@@ -283,12 +283,15 @@ int32_t  mrpdr_wave_encode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t 
                                    void *stream);
 /* Packet::decode_pdr_header (src/Packet.C:87-104): byte order of a header is its own
  * last byte.  Header i is hdrs + hdr_offsets[i] (or i*hdr_stride when hdr_offsets is
- * NULL), hdr_lens[i] long (or hdr_stride when NULL).  Outputs (any may be NULL):
+ * NULL), hdr_lens[i] long (or hdr_stride when NULL); hdrs_bytes is the size of the buffer hdrs
+ * points into -- offsets and lengths taken from a Message's size vector are untrusted, and a
+ * header that does not lie inside the buffer fails (ok[i] = 0) without being read.
+ * Outputs (any may be NULL):
  * stream_ids, tags, src_ranks, byteorders (u8), ndests (u64), dest_ranks (packet i's first
  * min(ndest, dest_stride) destinations at dest_ranks + i*dest_stride) and ok[i] = 1 when the
  * header parsed AND its format string equals f's. */
 int32_t  mrpdr_wave_decode_headers(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
-                                   const uint8_t *hdrs, const uint64_t *hdr_offsets,
+                                   const uint8_t *hdrs, uint64_t hdrs_bytes, const uint64_t *hdr_offsets,
                                    const uint64_t *hdr_lens, uint64_t hdr_stride,
                                    uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
                                    uint8_t *byteorders, uint64_t *ndests,

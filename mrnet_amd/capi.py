@@ -92,7 +92,7 @@ def load():
         "mrpdr_message_preamble_bytes": (u64, [u64]),
         "mrpdr_message_write_preamble": (i32, [vp, u64, u64, vp, vp, vp]),
         "mrpdr_message_parse_sizes": (i32, [vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64), vp]),
-        "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
+        "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "mrpdr_wave_filter": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
         "mrpdr_wave_filter_mixed": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, vp, vp, vp, vp]),
         "mrpdr_wave_decode_filter": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp, i32, i32, vp, vp, vp]),

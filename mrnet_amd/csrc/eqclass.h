@@ -16,7 +16,9 @@
 #define EQ_LOCAL 2048                 // keys one workgroup sorts in LDS (8 per thread)
 
 // keys[i] = value << 32 | i for the K = vals_offs[n] entries, all-ones padding up to kpad;
-// src_off is filled by a scan of the member counts afterwards.
+// src_off is filled by a scan of the member counts afterwards.  An entry without members leaves no
+// trace in the reference's map (the value is inserted by the first push_back, :841-845): it gets the
+// padding key and sorts out of the way with the padding.
 __global__ __launch_bounds__(MRPDR_TPB) void k_eq_keys(const uint32_t *vals, const uint64_t *vals_offs, uint64_t n,
                                                        uint64_t kpad, uint64_t *keys, const uint32_t *memcnts,
                                                        uint64_t *cnt64)
@@ -24,8 +26,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_eq_keys(const uint32_t *vals, con
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= kpad) return;
     const uint64_t k = vals_offs[n];
-    keys[i] = i < k ? ((uint64_t)vals[i] << 32 | i) : ~0ull;
-    cnt64[i] = i < k ? memcnts[i] : 0;
+    const uint32_t c = i < k ? memcnts[i] : 0;
+    keys[i] = c ? ((uint64_t)vals[i] << 32 | i) : ~0ull;
+    cnt64[i] = c;
 }
 
 // one compare-exchange step of the bitonic network over global memory (partner distance j >= EQ_LOCAL / 2)
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_eq_heads(const uint64_t *keys, co
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= kpad) return;
-    const uint64_t k = vals_offs[n];
+    (void)vals_offs; (void)n;
     uint64_t h = 0, c = 0;
-    if (i < k) {
+    if (keys[i] != ~0ull) {          // entries with members come first, sorted; the rest is padding
         h = (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32)) ? 1 : 0;
         c = cnt64[keys[i] & 0xFFFFFFFFull];
     }
@@ -93,7 +96,8 @@ struct EqOut {
 __global__ __launch_bounds__(MRPDR_TPB) void k_eq_emit(const uint64_t *keys, const uint64_t *vals_offs, uint64_t n,
                                                        uint64_t kpad, const uint64_t *head, const uint64_t *class_scan,
                                                        const uint64_t *dst_off, const uint64_t *src_off,
-                                                       const uint64_t *sorted_cnt, const uint32_t *mems, EqOut o)
+                                                       const uint64_t *sorted_cnt, const uint32_t *mems,
+                                                       const uint64_t *mems_offs, EqOut o)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     const uint64_t k = vals_offs[n];
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_eq_emit(const uint64_t *keys, con
             o.counts[c][0] = cnt; o.offs[c][0] = 0; o.offs[c][1] = cnt;
         }
     }
-    if (i >= k || !fits) return;
+    if (i >= k || !fits || keys[i] == ~0ull) return;
     const uint64_t cls = class_scan[i];                  // heads: index of the class this entry opens
     if (head[i]) {
         o.values[cls] = (uint32_t)(keys[i] >> 32);
@@ -115,6 +119,18 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_eq_emit(const uint64_t *keys, con
         while (e < k && !head[e]) e++;
         o.memcnts[cls] = (uint32_t)(dst_off[e] - dst_off[i]);
     }
-    const uint64_t src = src_off[keys[i] & 0xFFFFFFFFull], dst = dst_off[i];
-    for (uint64_t m = 0; m < sorted_cnt[i]; m++) o.mems[dst + m] = mems[src + m];
+    // The members of entry e of packet p start at mems_offs[p] + (members of p's entries before e):
+    // the reference restarts its member index for every packet (curClassMemIdx = 0, :834), so a
+    // packet whose mems array is longer than its counts add up to does not shift later packets.
+    const uint64_t e = keys[i] & 0xFFFFFFFFull;
+    uint64_t lo = 0, hi = n;                             // packet of entry e: vals_offs[p] <= e < vals_offs[p + 1]
+    while (hi - lo > 1) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (vals_offs[mid] <= e) lo = mid; else hi = mid;
+    }
+    const uint64_t src = mems_offs[lo] + (src_off[e] - src_off[vals_offs[lo]]), dst = dst_off[i];
+    const uint64_t have = mems_offs[n];
+    // counts that promise more members than the wave holds: the reference reads past its array;
+    // here such a member reads as 0
+    for (uint64_t m = 0; m < sorted_cnt[i]; m++) o.mems[dst + m] = src + m < have ? mems[src + m] : 0u;
 }

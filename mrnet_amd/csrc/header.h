@@ -40,7 +40,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_encode(HdrEncodeArgs a, HdrIm
 }
 
 struct HdrDecodeArgs {
-    const uint8_t *hdrs; const uint64_t *hdr_offsets; const uint64_t *hdr_lens; uint64_t hdr_stride;
+    const uint8_t *hdrs; uint64_t hdrs_bytes; const uint64_t *hdr_offsets; const uint64_t *hdr_lens; uint64_t hdr_stride;
     uint32_t *stream_ids; int32_t *tags; uint32_t *src_ranks; uint8_t *byteorders; uint64_t *ndests;
     uint32_t *dests; uint64_t dest_stride;
     int32_t *ok; uint64_t n;
@@ -50,8 +50,13 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_decode(HdrDecodeArgs a, HdrIm
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= a.n) return;
-    const uint8_t *p = a.hdrs + (a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride);
+    // offsets and lengths may come off the wire (a Message's size vector): a header that does
+    // not lie inside the buffer fails without being read
+    const uint64_t at = a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride;
     uint64_t space = a.hdr_lens ? a.hdr_lens[i] : a.hdr_stride;
+    const bool inside = at <= a.hdrs_bytes && space <= a.hdrs_bytes - at;
+    const uint8_t *p = a.hdrs + (inside ? at : 0);
+    if (!inside) space = 0;
     bool good = space >= 1;
     const bool swap = good && p[space - 1] != (uint8_t)MRPDR_LITTLEENDIAN;
     uint32_t sid = 0, src = 0, flen = 0;

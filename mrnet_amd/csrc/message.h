@@ -30,16 +30,20 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_msg_preamble(uint8_t *msg, uint64
     }
 }
 
-// sizes[2n] as received -> hdr_lens, buf_lens and (in buf_offsets, as scratch) hdr+buf per packet
-__global__ __launch_bounds__(MRPDR_TPB) void k_msg_split(const uint8_t *sizes, uint64_t n, uint64_t *hdr_lens,
-                                                         uint64_t *buf_lens, uint64_t *pair)
+// sizes[2n] as received -> hdr_lens, buf_lens and (in buf_offsets, as scratch) hdr+buf per packet.
+// The sizes are untrusted: each enters the sum as at most `clamp` = 2^63 / (n + 1), so neither a pair
+// nor the scan over the pairs can wrap; a clamped size makes the payload total larger than any
+// message that exists, which the length check of the caller (and the bounds checks of the header
+// and data decoders, who get the sizes as received) then refuse.
+__global__ __launch_bounds__(MRPDR_TPB) void k_msg_split(const uint8_t *sizes, uint64_t n, uint64_t clamp,
+                                                         uint64_t *hdr_lens, uint64_t *buf_lens, uint64_t *pair)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     if (i >= n) return;
     const uint64_t h = ld_u<uint64_t>(sizes + 16 * i), b = ld_u<uint64_t>(sizes + 16 * i + 8);
     hdr_lens[i] = h;
     buf_lens[i] = b;
-    pair[i] = h + b;
+    pair[i] = (h < clamp ? h : clamp) + (b < clamp ? b : clamp);
 }
 
 // hdr_offsets[n+1] = scan of the pairs; the data of packet i follows its header

@@ -416,7 +416,7 @@ static int32_t fill_wire(const char *who, const mrpdr_fmt *f, const mrpdr_wire *
         if (w->stride < f->dev.fixed_bytes)
             return fail("%s: stride %llu is shorter than the packet (%u bytes)", who,
                         (unsigned long long)w->stride, f->dev.fixed_bytes);
-        if (n && n * w->stride > w->bytes) return fail("%s: arena too small for %llu packets", who, (unsigned long long)n);
+        if (n && w->stride > w->bytes / n) return fail("%s: arena too small for %llu packets", who, (unsigned long long)n);
     }
     return 1;
 }
@@ -598,13 +598,27 @@ static CopyArgs make_copy_args(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &
     return a;
 }
 
+// a column without room while the wave holds elements of the field: status bit 0
+__global__ void k_cap_check(const uint64_t *offs, uint64_t n, uint32_t *status)
+{
+    if (offs[n] != 0) atomicOr(status, 1u);
+}
+
 template <bool ENCODE>
 static int32_t copy_field(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, int field,
                           uint64_t n, bool swap, hipStream_t st, int mode = COPY_BOTH)
 {
     const FieldDev &fd = f->dev.f[field];
     CopyArgs a = make_copy_args(c, f, wd, cd, field, n);
-    if (n == 0 || a.dense_cap == 0) return 1;
+    if (n == 0) return 1;
+    if (a.dense_cap == 0) {
+        // nothing can be moved; a decode must still say so when the wave does hold elements
+        if (!ENCODE) {
+            k_cap_check<<<1, 1, 0, st>>>(a.seg_offs, n, c->status);
+            LAUNCHED("k_cap_check");
+        }
+        return 1;
+    }
     // raw bytes and strings are never reversed (src/pdr_mem.c:394-412)
     const bool sw = swap && fd.width > 1 && !ENCODE;
     switch (fd.width) {
@@ -935,7 +949,7 @@ extern "C" int32_t mrpdr_wave_encode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
 }
 
 extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n,
-                                             const uint8_t *hdrs, const uint64_t *hdr_offsets,
+                                             const uint8_t *hdrs, uint64_t hdrs_bytes, const uint64_t *hdr_offsets,
                                              const uint64_t *hdr_lens, uint64_t hdr_stride,
                                              uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
                                              uint8_t *byteorders, uint64_t *ndests,
@@ -947,7 +961,7 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
     if (!make_image("mrpdr_wave_decode_headers", f, &img)) return 0;
     if (n == 0) return 1;
     if (!hdrs) return fail("mrpdr_wave_decode_headers: NULL input");
-    HdrDecodeArgs a = { hdrs, hdr_offsets, hdr_lens, hdr_stride, stream_ids, tags, src_ranks,
+    HdrDecodeArgs a = { hdrs, hdrs_bytes, hdr_offsets, hdr_lens, hdr_stride, stream_ids, tags, src_ranks,
                         byteorders, ndests, dest_ranks, dest_stride, ok, n };
     k_hdr_decode<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(a, img);
     LAUNCHED("k_hdr_decode");
@@ -981,7 +995,7 @@ extern "C" int32_t mrpdr_message_parse_sizes(mrpdr_ctx *c, const uint8_t *sizes,
         return fail("mrpdr_message_parse_sizes: NULL argument");
     hipStream_t st = (hipStream_t)stream;
     if (n) {
-        k_msg_split<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(sizes, n, hdr_lens, buf_lens, buf_offsets);
+        k_msg_split<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(sizes, n, (1ull << 63) / (n + 1), hdr_lens, buf_lens, buf_offsets);
         LAUNCHED("k_msg_split");
     }
     if (!run_scan(c, buf_offsets, n, 1, 0, hdr_offsets, st)) return 0;
@@ -1493,6 +1507,7 @@ extern "C" int32_t mrpdr_wave_int_eq_class(mrpdr_ctx *c, const mrpdr_column *val
             return fail("mrpdr_wave_int_eq_class: output column %d needs counts, offs and values", k);
     if (out_memcnts->capacity < out_vals->capacity) return fail("mrpdr_wave_int_eq_class: out_memcnts smaller than out_vals");
     const uint64_t entries = vals->capacity;          // upper bound of the class entries of the wave
+    if (entries >= 0xFFFFFFFFull) return fail("mrpdr_wave_int_eq_class: 2^32 - 1 class entries or more");
     const uint64_t kpad = eq_pad(entries);
     if (kpad > c->max_packets) return fail("mrpdr_wave_int_eq_class: %llu class entries exceed the ctx limit",
                                            (unsigned long long)entries);
@@ -1530,7 +1545,7 @@ extern "C" int32_t mrpdr_wave_int_eq_class(mrpdr_ctx *c, const mrpdr_column *val
     for (int k = 0; k < 3; k++) { o.counts[k] = outs[k]->counts; o.offs[k] = outs[k]->offs; }
     o.status = c->status;
     k_eq_emit<<<blocks, MRPDR_TPB, 0, st>>>(keys, vals->offs, n, kpad, head, class_scan, dst_off, src_off, sorted_cnt,
-                                            (const uint32_t *)mems->values, o);
+                                            (const uint32_t *)mems->values, mems->offs, o);
     LAUNCHED("k_eq_emit");
     return 1;
 }

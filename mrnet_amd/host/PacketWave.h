@@ -571,7 +571,8 @@ class PacketWave {
         DeviceBuffer d_sid, d_tag, d_src, d_bo, d_ok;
         d_sid.resize(4 * n_); d_tag.resize(4 * n_); d_src.resize(4 * n_); d_bo.resize(n_); d_ok.resize(4 * n_);
         const uint8_t *hdr_base = in_message_ ? d_msg_.ptr<uint8_t>() + msg_pre_ : d_hdrs_.ptr<uint8_t>();
-        if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, hdr_base, in_message_ ? d_hoffs_.ptr<uint64_t>() : nullptr,
+        const uint64_t hdr_bytes = in_message_ ? d_msg_.bytes() - msg_pre_ : d_hdrs_.bytes();
+        if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, hdr_base, hdr_bytes, in_message_ ? d_hoffs_.ptr<uint64_t>() : nullptr,
                                        in_message_ ? d_hlens_.ptr<uint64_t>() : nullptr, hdr_len_,
                                        d_sid.ptr<uint32_t>(), d_tag.ptr<int32_t>(), d_src.ptr<uint32_t>(),
                                        d_bo.ptr<uint8_t>(), nullptr, nullptr, 0, d_ok.ptr<int32_t>(), wc_.stream))

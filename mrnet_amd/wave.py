@@ -466,7 +466,8 @@ class Codec:
             "src_rank": self.empty(n, torch.int32), "byteorder": self.empty(n, torch.uint8),
             "ndest": self.empty(n, torch.int64), "ok": self.empty(n, torch.int32),
         }
-        r = self._lib.mrpdr_wave_decode_headers(self.handle, fmt.handle, n, _ptr(hdrs), _ptr(offsets),
+        r = self._lib.mrpdr_wave_decode_headers(self.handle, fmt.handle, n, _ptr(hdrs),
+                                                0 if hdrs is None else hdrs.numel(), _ptr(offsets),
                                                 _ptr(lens), stride, _ptr(out["stream_id"]),
                                                 _ptr(out["tag"]), _ptr(out["src_rank"]),
                                                 _ptr(out["byteorder"]), _ptr(out["ndest"]),

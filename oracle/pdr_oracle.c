@@ -1036,11 +1036,15 @@ int32_t orc_filter_perfdata(int op, int type, const int32_t *rank_vals, const ui
 /* ======================================================================= */
 /* tfilter_IntEqClass (src/FilterDefinitions.C:812-902)                     */
 /* ======================================================================= */
-typedef struct { uint32_t val; uint64_t order; uint32_t cnt; uint64_t first; } eq_entry;
+/* The reference pours members into std::map<unsigned, std::vector<unsigned>> one push_back at a
+ * time (:841-845): a class exists only once a member has been pushed under its value, so a class
+ * entry with a member count of 0 leaves no trace.  Restated as the list of (value, member) pairs in
+ * push order, ordered by value afterwards (the map's iteration order; push order inside a value). */
+typedef struct { uint32_t val; uint64_t order; uint32_t member; } eq_pair;
 
-static int eq_cmp(const void *a, const void *b)        /* std::map order; arrival order inside a key */
+static int eq_cmp(const void *a, const void *b)
 {
-    const eq_entry *x = (const eq_entry *)a, *y = (const eq_entry *)b;
+    const eq_pair *x = (const eq_pair *)a, *y = (const eq_pair *)b;
     if (x->val != y->val) return x->val < y->val ? -1 : 1;
     return x->order < y->order ? -1 : (x->order > y->order ? 1 : 0);
 }
@@ -1050,26 +1054,33 @@ int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts
                                 uint64_t n, uint32_t *out_vals, uint32_t *out_memcnts, uint32_t *out_mems,
                                 uint64_t *nclasses, uint64_t *nmems)
 {
-    uint64_t total = val_offs[n];
-    eq_entry *e = (eq_entry *)malloc((total ? total : 1) * sizeof *e);
+    uint64_t total = 0;
+    for (uint64_t p = 0; p < n; p++)
+        for (uint64_t j = 0; j < val_counts[p]; j++) total += memcnts[val_offs[p] + j];
+    eq_pair *e = (eq_pair *)malloc((total ? total : 1) * sizeof *e);
     uint64_t k = 0;
     for (uint64_t p = 0; p < n; p++) {                     /* :824-849 */
-        uint64_t cur = mem_offs[p];                        /* curClassMemIdx, per packet */
+        uint64_t cur = mem_offs[p];                        /* curClassMemIdx = 0: the packet's own mems array */
         for (uint64_t j = 0; j < val_counts[p]; j++) {
             uint64_t at = val_offs[p] + j;
-            e[k].val = vals[at]; e[k].order = k; e[k].cnt = memcnts[at]; e[k].first = cur;
+            for (uint32_t m = 0; m < memcnts[at]; m++) {   /* classes[vals[j]].push_back(mems[cur + m]) */
+                /* a packet whose member counts promise more than the wave's mems hold: the
+                 * reference reads past its array; here such a member reads as 0 */
+                e[k].val = vals[at]; e[k].order = k;
+                e[k].member = cur + m < mem_offs[n] ? mems[cur + m] : 0;
+                k++;
+            }
             cur += memcnts[at];
-            k++;
         }
     }
     qsort(e, (size_t)total, sizeof *e, eq_cmp);
-    uint64_t nc = 0, nm = 0;
+    uint64_t nc = 0;
     for (uint64_t i = 0; i < total; i++) {                 /* :852-875 */
         if (i == 0 || e[i].val != e[i - 1].val) { out_vals[nc] = e[i].val; out_memcnts[nc] = 0; nc++; }
-        out_memcnts[nc - 1] += e[i].cnt;
-        for (uint32_t m = 0; m < e[i].cnt; m++) out_mems[nm++] = mems[e[i].first + m];
+        out_memcnts[nc - 1]++;
+        out_mems[i] = e[i].member;
     }
-    *nclasses = nc; *nmems = nm;
+    *nclasses = nc; *nmems = total;
     free(e);
     return 1;
 }

@@ -104,3 +104,72 @@ def test_filter_calls_refuse_bad_arguments(codec):
     refused(lib.mrpdr_ctx_perf_plain_copy(h, res.data_ptr() + 1, v.data_ptr(), 16, 1, C.byref(ms), st), "multiples of 16")
     torch.cuda.synchronize()
     assert codec.status() == 0
+
+
+def test_untrusted_sizes_cannot_reach_memory(codec):
+    """Offsets and lengths that come off the wire (a Message's size vector) are data, not
+    arguments: a header outside its buffer fails as a packet, a size vector whose entries would
+    wrap the offsets is refused by the length check, a stride times n that wraps is refused."""
+    from wavegen import O
+    lib, h = capi.load(), codec.handle
+    fmt = W.Format("%d")
+    n = 6
+    hdr = O.header_encode(9, 100, 1, "%d")
+    L = hdr.size
+    blob = np.concatenate([hdr] * n)
+    offs = (np.arange(n, dtype=np.uint64) * np.uint64(L))
+    lens = np.full(n, L, np.uint64)
+    offs[1] = np.uint64(n * L)                 # starts at the end of the buffer
+    offs[2] = np.uint64(2**64 - 8)             # offset + length wraps
+    lens[3] = np.uint64(2**63)                 # longer than the buffer
+    offs[4] = np.uint64(n * L - L + 1)         # last byte outside
+    out = codec.decode_headers(fmt, n, codec.to_device(blob), offsets=codec.to_device(offs), lens=codec.to_device(lens))
+    torch.cuda.synchronize()
+    assert W.Codec.to_numpy(out["ok"]).tolist() == [1, 0, 0, 0, 0, 1]
+    # a message whose size vector announces absurd packets
+    vals = np.arange(n, dtype=np.int32)
+    msg = codec.message_build(fmt, codec.columns_from_numpy(fmt, [vals]), n)
+    good = W.Codec.to_numpy(msg).copy()
+    for at, val in ((5 + 16 * 2, 2**64 - 1), (5 + 16 * 3 + 8, 2**63 + 5), (5, 2**62)):
+        bad = good.copy()
+        bad[at:at + 8] = np.frombuffer(int(val).to_bytes(8, "little"), np.uint8)
+        with pytest.raises(W.PdrError):
+            codec.message_parse(fmt, codec.to_device(bad))
+    bad = good.copy()                          # every size huge: the sum must not wrap into something small
+    for i in range(2 * n):
+        bad[5 + 8 * i:13 + 8 * i] = 0xFF
+    with pytest.raises(W.PdrError):
+        codec.message_parse(fmt, codec.to_device(bad))
+    nn, hd, wire = codec.message_parse(fmt, msg)
+    assert nn == n and bool(hd["ok"].all())
+    # n * stride wraps around 2^64
+    arena = torch.zeros(64, dtype=torch.uint8, device=codec.device)
+    col = (capi.Column * 1)()
+    v = torch.zeros(n, dtype=torch.int32, device=codec.device)
+    col[0] = capi.Column(v.data_ptr(), None, None, n, None, None, 0)
+    wrap = capi.Wire(arena.data_ptr(), None, None, (1 << 63) + 8, 64)
+    ok = torch.zeros(n, dtype=torch.int32, device=codec.device)
+    refused(lib.mrpdr_wave_decode(h, fmt.handle, C.byref(wrap), 2, 0, col, ok.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream), "arena too small")
+    torch.cuda.synchronize()
+    assert codec.status() == 0
+
+
+def test_column_without_room_is_reported(codec):
+    """A variable field decoded into a column of capacity 0 while the wave holds elements: nothing
+    can be written, and status bit 0 says so (the long-payload path, which plans chunks from the
+    capacity, and the short-packet tiles alike)."""
+    from wavegen import O, make_wave
+    for fmt_s, count in (("%d %ad", 3), ("%ad", 5000)):
+        n = 40
+        fmt = W.Format(fmt_s)
+        ocols = make_wave(fmt_s, n, 3, max_count=count, counts={len(fmt) - 1: np.full(n, count, np.uint64)})
+        arena, offs, lens = O.wave_encode(fmt_s, ocols, n)
+        wire = W.WireWave(codec.to_device(arena), n, codec.to_device(offs), codec.to_device(lens), 0)
+        cols = codec.alloc_columns(fmt, n)            # capacities 0: no values buffers
+        ok = codec.empty(n, torch.int32)
+        codec.decode_into(fmt, wire, cols, ok)
+        torch.cuda.synchronize()
+        assert int(W.Codec.to_numpy(cols[-1].offs).view(np.uint64)[n]) == n * count
+        assert codec.status() & 1, fmt_s
+        assert codec.status() == 0                    # reading cleared it

@@ -137,6 +137,60 @@ def test_int_eq_class(codec, n, kmax, vrange, mmax):
     assert codec.status() == 0
 
 
+def _eq_class_by_map(kc, vals, mc, ec, mems):
+    """The reference's loops, literally (src/FilterDefinitions.C:824-875): a map from value to the
+    members pushed under it; the member index restarts at 0 for every packet; a class is created
+    by its first push_back, so a class entry with no members never appears."""
+    classes = {}
+    ko = np.concatenate([[0], np.cumsum(kc)]).astype(np.int64)
+    eo = np.concatenate([[0], np.cumsum(ec)]).astype(np.int64)
+    for p in range(len(kc)):
+        cur = 0
+        for j in range(ko[p], ko[p + 1]):
+            for k in range(int(mc[j])):
+                classes.setdefault(int(vals[j]), []).append(int(mems[eo[p] + cur + k]))
+            cur += int(mc[j])
+    keys = sorted(classes)
+    return (np.array(keys, np.uint32), np.array([len(classes[k]) for k in keys], np.uint32),
+            np.array([m for k in keys for m in classes[k]], np.uint32))
+
+
+@pytest.mark.parametrize("case", ["zero_member_classes", "surplus_members", "both", "all_empty"])
+def test_int_eq_class_follows_the_reference_map(codec, case):
+    """Two things the std::map loops do that a sort-based merge has to reproduce on purpose: a class
+    entry whose member count is 0 leaves no class behind (also when EVERY entry of that value is
+    empty), and a packet whose mems array is longer than its member counts add up to does not
+    shift the members of later packets.  Expected side: the map loops written out in the test."""
+    n = 700
+    kc = (splitmix64(3, n) % np.uint64(4)).astype(np.uint64)
+    K = int(kc.sum())
+    vals = (splitmix64(4, K) % np.uint64(60)).astype(np.uint32)
+    mc = (splitmix64(5, K) % np.uint64(4) + np.uint64(1)).astype(np.uint32)
+    if case in ("zero_member_classes", "both"):
+        mc[vals % 7 == 3] = 0                         # every entry of these values is empty
+        mc[::5] = 0                                   # and some entries of other values
+    if case == "all_empty":
+        mc[:] = 0
+    ko = np.zeros(n + 1, np.int64); np.cumsum(kc, out=ko[1:])
+    need = np.array([int(mc[ko[i]:ko[i + 1]].sum()) for i in range(n)], np.uint64)
+    ec = need.copy()
+    if case in ("surplus_members", "both"):
+        ec += (splitmix64(6, n) % np.uint64(3)).astype(np.uint64)     # 0-2 members nobody claims
+    mems = (splitmix64(7, int(ec.sum())) % np.uint64(1 << 24)).astype(np.uint32)
+    want = _eq_class_by_map(kc, vals, mc, ec, mems)
+    orc = O.filter_int_eq_class((kc, vals), (kc, mc), (ec, mems))
+    for w, o in zip(want, orc):
+        assert np.array_equal(w, o), "oracle differs from the map loops"
+    wave = P.PacketWave(codec, 3, 100, "%aud %aud %aud", [(kc, vals), (kc, mc), (ec, mems)], n)
+    out = P.tfilter_IntEqClass(wave)
+    cols = out.unpack("%aud %aud %aud")
+    torch.cuda.synchronize()
+    for c, w in zip(cols, want):
+        cnt = int(W.Codec.to_numpy(c.counts).view(np.uint64)[0])
+        assert cnt == w.size and np.array_equal(W.Codec.to_numpy(c.values).view(np.uint32)[:cnt], w), case
+    assert codec.status() == 0
+
+
 def test_perfdata_concat(codec):
     """TFILTER_ARRAY_CONCAT in tfilter_PerfData (src/FilterDefinitions.C:1000-1008, 1171-1203):
     packets without data drop out with their rank and nelems arrays."""

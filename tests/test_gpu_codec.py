@@ -380,6 +380,64 @@ def test_full_size_array_wave_properties(codec):
     assert codec.status() == 0
 
 
+def test_headline_wave_at_its_full_size(codec):
+    """The wave the GB/s figure is quoted on, at its real size: 4,096 packets of '%af' with
+    65,536 floats each from a big-endian sender (1 GiB of payload) -- decode, sizeof into the
+    cache-line phased arena the benchmark uses, encode.  Checked through properties that do not
+    depend on the size (decode = element-wise byte reversal of the wire; encode(decode(x)) = the
+    little-endian wire of the same values; counts, offsets, lengths), plus three whole packets
+    (first, one from the middle, last) through the oracle, byte for byte, both directions."""
+    n, m = 4096, 65536
+    fmt_s = "%af"
+    fmt = W.Format(fmt_s)
+    stride = 8 + 4 * m
+    g = torch.Generator(device="cuda").manual_seed(33)
+    be = torch.empty((n, stride), dtype=torch.uint8, device="cuda")
+    be[:, :8] = torch.tensor(list(int(m).to_bytes(8, "big")), dtype=torch.uint8, device="cuda")
+    for a in range(0, n, 512):                       # in slices: the generator's scratch stays small
+        v = torch.randint(-2**31, 2**31 - 1, (512, m), dtype=torch.int32, device="cuda", generator=g)
+        be[a:a + 512, 8:] = v.view(torch.uint8).view(512, m, 4).flip(-1).reshape(512, 4 * m)
+        del v
+    offs = torch.arange(n + 1, dtype=torch.int64, device="cuda") * stride
+    lens = torch.full((n,), stride, dtype=torch.int64, device="cuda")
+    wire = W.WireWave(be.view(-1), n, offs, lens, 0)
+    cols = [W.Column(torch.empty(n * m, dtype=torch.int32, device="cuda"), torch.empty(n, dtype=torch.int64, device="cuda"),
+                     torch.empty(n + 1, dtype=torch.int64, device="cuda"), capacity=n * m)]
+    ok = torch.empty(n, dtype=torch.int32, device="cuda")
+    codec.decode_into(fmt, wire, cols, ok, W.BIGENDIAN)
+    assert bool(ok.all()) and bool((cols[0].counts == m).all())
+    assert torch.equal(cols[0].offs, torch.arange(n + 1, dtype=torch.int64, device="cuda") * m)
+    vals = cols[0].values.view(n, m)
+    for a in range(0, n, 512):
+        want = be[a:a + 512, 8:].reshape(512, m, 4).flip(-1).reshape(512, 4 * m).contiguous().view(torch.int32)
+        assert torch.equal(vals[a:a + 512], want), "decode is not the element-wise byte reversal"
+        del want
+    align = 128
+    phase = codec.payload_phase(fmt, align)
+    slot = (phase + stride + align - 1) // align * align
+    out_lens, out_offs, total = codec.sizeof(fmt, cols, n, align, phase)
+    assert total == n * slot and bool((out_lens == stride).all())
+    assert torch.equal(out_offs[:n], torch.arange(n, dtype=torch.int64, device="cuda") * slot + phase)
+    dst = W.WireWave(torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda"), n, out_offs, out_lens, 0)
+    codec.encode_into(fmt, cols, dst)
+    rows = dst.arena.view(n, slot)
+    assert bool((rows[:, phase:phase + 8].contiguous().view(torch.int64) == m).all())
+    for a in range(0, n, 512):
+        got = rows[a:a + 512, phase + 8:phase + stride].contiguous().view(torch.int32)
+        assert torch.equal(got, vals[a:a + 512]), "encode is not the little-endian wire of the decoded values"
+        del got
+    assert bool((rows[:, :phase] == 0xEE).all()) and bool((rows[:, phase + stride:] == 0xEE).all())
+    assert codec.status() == 0
+    # whole packets through the oracle
+    for i in (0, 2049, n - 1):
+        pkt = W.Codec.to_numpy(be[i])
+        dec, ook = O.wave_decode(fmt_s, pkt, np.array([0, stride], np.uint64), np.array([stride], np.uint64), O.BIG)
+        assert bool(ook.all()) and int(dec[0]["counts"][0]) == m
+        assert W.Codec.to_numpy(vals[i]).tobytes() == dec[0]["values"].tobytes(), i
+        enc, _, _ = O.wave_encode(fmt_s, dec, 1)
+        assert W.Codec.to_numpy(rows[i, phase:phase + stride]).tobytes() == enc.tobytes(), i
+
+
 @pytest.mark.parametrize("fmt_s,n,giant_every,giant,small", [("%auc", 3000, 100, 1000000, 40),
                                                              ("%ad", 30000, 10000, 7000000, 1),
                                                              ("%hd %s %ahd", 2000, 500, 3000000, 9)])

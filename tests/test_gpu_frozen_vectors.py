@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from wavegen import columns_equal, make_wave, random_values
+from wavegen import columns_equal, make_wave, random_values, to_sender_order
 from test_gpu_codec import dev_cols, host_cols, wire_from_numpy
 
 pytestmark = pytest.mark.gpu
@@ -54,6 +54,10 @@ def test_truncation_at_every_length(codec, frozen):
     offs = np.zeros(m + 1, np.uint64)
     _, ok = codec.decode(fmt, wire_from_numpy(codec, m, full, offs, lens), W.LITTLEENDIAN)
     assert W.Codec.to_numpy(ok).tolist() == t["ok_le"]
+    # the same packet as a big-endian sender wrote it, cut at every length, decoded with reversal
+    be = to_sender_order(fmt_s, full, np.array([0, full.size], np.uint64), np.array([full.size], np.uint64))
+    _, ok = codec.decode(fmt, wire_from_numpy(codec, m, be, offs, lens), W.BIGENDIAN)
+    assert W.Codec.to_numpy(ok).tolist() == t["ok_be"]
 
 
 def test_three_packet_message(codec, frozen):
