@@ -731,6 +731,43 @@ extern "C" int32_t mrpdr_wave_encode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
 // ---------------------------------------------------------------------------
 // decode
 // ---------------------------------------------------------------------------
+// The three launches of the tile decode.
+static int32_t launch_tile_walk(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, uint64_t n,
+                                bool swap, int32_t *ok, hipStream_t st)
+{
+    const uint32_t tiles = blocks_for(n, TILE_PKTS);
+    const bool small = f->tv.nv <= TILE_SMALLV;
+    if (swap) { if (small) k_tile_walk<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+                else       k_tile_walk<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
+    else      { if (small) k_tile_walk<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+                else       k_tile_walk<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
+    LAUNCHED("k_tile_walk");
+    return 1;
+}
+
+static int32_t launch_tile_offs(mrpdr_ctx *c, const mrpdr_fmt *f, const ColsDev &cd, uint64_t n, hipStream_t st)
+{
+    k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt,
+                                                                                                 c->ntile_cnt);
+    LAUNCHED("k_tile_offs");
+    return 1;
+}
+
+static int32_t launch_tile_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, uint64_t n,
+                                  bool swap, hipStream_t st)
+{
+    bool timed;
+    if (!perf_begin(c, st, &timed, 0)) return 0;
+    const bool small = f->tv.nv <= TILE_SMALLV;
+    const uint32_t tiles = blocks_for(n, TILE_PKTS);
+    if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+                else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
+    else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
+                else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
+    LAUNCHED("k_tile_decode");
+    return perf_end(c, st, timed, 0);
+}
+
 // orders (optional, device, n bytes): the sender byte order of every packet; sender_bo is then unused.
 // Such a wave takes the one-lane-per-packet walk and the chunk copy (no LDS-staged rows or tiles):
 // waves of both kinds come from trees that span machine types, not from the bandwidth-bound case.
@@ -765,15 +802,8 @@ static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, c
             }
             LAUNCHED("k_rows_decode");
         } else if (!orders && tile_path_ok(f, wd, n)) {
-            const uint32_t tiles = blocks_for(n, TILE_PKTS);
-            const bool small = f->tv.nv <= TILE_SMALLV;
-            if (swap) { if (small) k_tile_walk<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-                        else       k_tile_walk<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
-            else      { if (small) k_tile_walk<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-                        else       k_tile_walk<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
-            LAUNCHED("k_tile_walk");
-            k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt, c->ntile_cnt);
-            LAUNCHED("k_tile_offs");
+            if (!launch_tile_walk(c, f, wd, cd, n, swap, ok, st)) return 0;
+            if (!launch_tile_offs(c, f, cd, n, st)) return 0;
             for (int i = 0; totals_host && i < f->dev.nf; i++)
                 if (f->dev.f[i].kind != MRPDR_SCALAR)
                     HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -819,16 +849,7 @@ static int32_t decode_finish(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
     hipStream_t st = (hipStream_t)stream;
     const bool swap = !orders && sender_bo != MRPDR_LITTLEENDIAN;
     if (!orders && tile_path_ok(f, wd, n)) {
-        bool timed;
-        if (!perf_begin(c, st, &timed, 0)) return 0;
-        const uint32_t tiles = blocks_for(n, TILE_PKTS);
-        const bool small = f->tv.nv <= TILE_SMALLV;
-        if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
-                    else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
-        else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
-                    else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
-        LAUNCHED("k_tile_decode");
-        return perf_end(c, st, timed, 0);
+        return launch_tile_decode(c, f, wd, cd, n, swap, st);
     }
     for (int i = 0; i < f->dev.nf; i++) {
         if (f->dev.f[i].kind == MRPDR_STRING_ARRAY) {

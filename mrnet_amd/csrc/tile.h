@@ -121,6 +121,17 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         if (t == 0 && (m.end[np - 1] < s || m.end[np - 1] - s + 32 > TILE_IMG)) fine = false;   // fits the image
         if (!fine) m.staged = 0;
         if (t + 1 < np && m.start[t + 1] != e) m.packed = 0;
+        if (SEGS && CAPS) {
+            // offs[] is the caller's between the two halves of a decode: whatever it holds, no packet
+            // moves more bytes than it has, backwards, or beyond the column
+            bool sane = true;
+            const uint64_t room = (e >= s && s <= wire.bytes && e - s <= wire.bytes - s) ? e - s : 0;
+            for (int v = 0; v < tv.nv; v++) {
+                const uint64_t a = m.seg[v][t], b = m.seg[v][t + 1];
+                sane = sane && b >= a && (b - a) <= room && (b - a) * (uint64_t)tv.width[v] <= room && b <= cols.cap[tv.field[v]];
+            }
+            if (!sane) m.too_small = 1;
+        }
     }
     if (over) m.too_small = 1;
     __syncthreads();
@@ -604,10 +615,11 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
-    // a column too small for the wave: nothing is written, the status word says so
+    // a column too small for the wave, or offs[] that do not describe these packets: nothing is
+    // written, the status word says so
     tile_load_meta<true, true>(m, tv, wire, cols, p0, np, n);
     if (m.too_small) {
-        if (blockIdx.x == 0 && t == 0) atomicOr(status, 1u);
+        if (t == 0) atomicOr(status, 1u);
         return;
     }
     const bool staged = m.staged != 0;
@@ -629,3 +641,4 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     if (staged) tile_copy_fields<true, false, SWAP>(m, img, fmt, tv, wire, cols, np);
     else        tile_copy_fields<false, false, SWAP>(m, img, fmt, tv, wire, cols, np);
 }
+
