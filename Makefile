@@ -7,9 +7,10 @@ LIB      = mrnet_amd/lib/libmrpdr.so
 
 HOSTTEST = tests/host/test_packet_wave
 CTEST    = tests/host/test_c_abi
+PLUGTEST = tests/host/test_plugin
 ROCM    ?= /opt/rocm
 
-all: $(LIB) oracle $(HOSTTEST) $(CTEST)
+all: $(LIB) oracle $(HOSTTEST) $(CTEST) plugin-check $(PLUGTEST)
 
 $(LIB): $(SRC)/mrpdr.hip $(wildcard $(SRC)/*.h) include/mrpdr.h
 	mkdir -p mrnet_amd/lib
@@ -28,8 +29,20 @@ $(CTEST): tests/host/test_c_abi.c include/mrpdr.h $(LIB)
 	gcc -std=c99 -O2 -Wall -Wextra -o $@ tests/host/test_c_abi.c -Lmrnet_amd/lib -lmrpdr \
 		-L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib' -Wl,-rpath,$(ROCM)/lib
 
+# The plugin run without MRNet: tests/host/test_plugin.cpp implements the Packet methods it calls
+$(PLUGTEST): tests/host/test_plugin.cpp integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h include/mrpdr.h $(LIB)
+	g++ -std=c++11 -O2 -Wall -D__HIP_PLATFORM_AMD__ -Iintegration/buildcheck -Iinclude -I$(ROCM)/include -o $@ \
+		tests/host/test_plugin.cpp -Lmrnet_amd/lib -lmrpdr -L$(ROCM)/lib -lamdhip64 \
+		-Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib' -Wl,-rpath,$(ROCM)/lib
+
+# The MRNet filter plugin compiles (objects only: it links against a real MRNet tree, which is not
+# here).  integration/buildcheck/ holds a stand-in for the few MRNet declarations it uses.
+plugin-check: integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h include/mrpdr.h
+	g++ -std=c++11 -Wall -Wextra -fPIC -fsyntax-only -D__HIP_PLATFORM_AMD__ -Iintegration/buildcheck -Iinclude \
+		-I$(ROCM)/include integration/mrpdr_filters.C
+
 clean:
-	rm -f $(LIB) $(HOSTTEST) $(CTEST)
+	rm -f $(LIB) $(HOSTTEST) $(CTEST) $(PLUGTEST)
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean plugin-check

@@ -1,0 +1,224 @@
+// mrpdr_filters.C -- MRNet filter plugin: the built-in transformation filters TFILTER_SUM /
+// MIN / MAX / AVG computed on an MI355X through libmrpdr.
+//
+// Loaded like any user filter (src/Network.C:1887, src/Filter.C:139-207):
+//
+//     int id = net->load_FilterFunc("libmrpdr_filters.so", "mrpdr_Sum");
+//     Stream* s = net->new_Stream(comm, id, SFILTER_WAITFORALL);
+//
+// and called by Filter::push_Packets (src/Filter.C:42-117) with one wave: the packets the
+// synchronisation filter released, one per child.  The plugin ABI is src/Filter.h:64-68; the
+// `<name>_format_string` symbols are required by the loader (src/Filter.C:175-183).
+//
+// Each function accepts what its built-in twin accepts (src/FilterDefinitions.C:90-645): packets of
+// exactly one scalar token ("%d", "%lf", ...), for Avg a scalar followed by "%d"; all packets of a
+// wave must share one format (the built-ins assert it, :104-105; here a wave that does not is
+// dropped with a message).  The result is ONE packet with the stream id, tag and format of the
+// first input, holding what one call of the built-in over the same wave computes, bit for bit
+// (mrpdr_wave_filter with MRPDR_SHAPE_FLAT).  Packets from senders of the other byte order are
+// handled per packet, as Packet::decode_pdr_data does (src/Packet.C:118).
+//
+// Build inside an MRNet tree:
+//     g++ -shared -fPIC integration/mrpdr_filters.C -I<mrnet>/include -I<mrnet>/xplat/include
+//         -I<mrnet>/external/boost/include -I<repo>/include -I/opt/rocm/include
+//         -D__HIP_PLATFORM_AMD__ -L<repo>/mrnet_amd/lib -lmrpdr -L/opt/rocm/lib -lamdhip64
+//         -o libmrpdr_filters.so
+// `make plugin-check` compiles this file against integration/buildcheck/mrnet/MRNet.h, a
+// stand-in that declares only the handful of MRNet names used below (it is a build check of this
+// file, not MRNet).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "mrnet/MRNet.h"
+#include "mrpdr.h"
+#include <hip/hip_runtime_api.h>
+
+using namespace MRN;
+
+namespace {
+
+// Per (stream, filter) state, kept by MRNet in `void** filter_state` between waves.
+struct GpuFilterState {
+    mrpdr_ctx  *ctx;
+    mrpdr_fmt  *fmt;          // compiled format of the stream's packets
+    char       *fmt_text;
+    hipStream_t stream;
+    uint8_t    *h_rows;       // pinned: the data buffers of the wave, one row per packet
+    uint8_t    *h_orders;     // pinned: sender byte order of every packet
+    uint8_t    *d_rows, *d_orders, *d_result;
+    int32_t    *d_ok;
+    size_t      cap_packets;
+};
+
+const uint64_t MAX_WAVE = 1u << 22;
+
+bool hip_ok(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return true;
+    fprintf(stderr, "mrpdr filter: %s: %s\n", what, hipGetErrorString(e));
+    return false;
+}
+
+void release(GpuFilterState *st)
+{
+    if (!st) return;
+    if (st->h_rows) (void)hipHostFree(st->h_rows);
+    if (st->h_orders) (void)hipHostFree(st->h_orders);
+    if (st->d_rows) (void)hipFree(st->d_rows);
+    if (st->d_orders) (void)hipFree(st->d_orders);
+    if (st->d_result) (void)hipFree(st->d_result);
+    if (st->d_ok) (void)hipFree(st->d_ok);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    if (st->fmt) mrpdr_fmt_free(st->fmt);
+    if (st->ctx) mrpdr_ctx_destroy(st->ctx);
+    free(st->fmt_text);
+    delete st;
+}
+
+// The state of this stream, created on the first wave, re-made when the stream's format changes.
+GpuFilterState *state_for(void **slot, const char *fmt_text)
+{
+    GpuFilterState *st = static_cast<GpuFilterState *>(*slot);
+    if (st && strcmp(st->fmt_text, fmt_text) == 0) return st;
+    release(st);
+    *slot = NULL;
+    st = new GpuFilterState();
+    memset(st, 0, sizeof *st);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    st->ctx = mrpdr_ctx_create(device, MAX_WAVE);
+    st->fmt = mrpdr_fmt_compile(fmt_text);
+    st->fmt_text = strdup(fmt_text);
+    if (!st->ctx || !st->fmt || !st->fmt_text ||
+        !hip_ok(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking), "hipStreamCreate") ||
+        !hip_ok(hipMalloc((void **)&st->d_result, 16), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&st->d_ok, sizeof(int32_t)), "hipMalloc")) {
+        fprintf(stderr, "mrpdr filter: %s\n", mrpdr_last_error());
+        release(st);
+        return NULL;
+    }
+    *slot = st;
+    return st;
+}
+
+bool grow(GpuFilterState *st, size_t n, size_t row)
+{
+    if (n <= st->cap_packets) return true;
+    size_t cap = st->cap_packets ? st->cap_packets : 1024;
+    while (cap < n) cap *= 2;
+    if (st->h_rows) (void)hipHostFree(st->h_rows);
+    if (st->h_orders) (void)hipHostFree(st->h_orders);
+    if (st->d_rows) (void)hipFree(st->d_rows);
+    if (st->d_orders) (void)hipFree(st->d_orders);
+    st->h_rows = st->h_orders = st->d_rows = st->d_orders = NULL;
+    st->cap_packets = 0;
+    if (!hip_ok(hipHostMalloc((void **)&st->h_rows, cap * row, hipHostMallocDefault), "hipHostMalloc") ||
+        !hip_ok(hipHostMalloc((void **)&st->h_orders, cap, hipHostMallocDefault), "hipHostMalloc") ||
+        !hip_ok(hipMalloc((void **)&st->d_rows, cap * row), "hipMalloc") ||
+        !hip_ok(hipMalloc((void **)&st->d_orders, cap), "hipMalloc"))
+        return false;
+    st->cap_packets = cap;
+    return true;
+}
+
+// One wave through TFILTER_<op>.  Nothing is pushed to `out` when the filter has nothing to emit
+// (a format it does not accept, a failure), as the built-ins do after logging.
+void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, void **state)
+{
+    const size_t n = in.size();
+    if (n == 0) return;
+    if (n > MAX_WAVE) { fprintf(stderr, "%s: a wave of %zu packets is beyond this plugin's limit\n", name, n); return; }
+    const char *fmt_text = in[0]->get_FormatString();
+    GpuFilterState *st = state_for(state, fmt_text);
+    if (!st) return;
+    // "%T" for Sum / Min / Max, "%T %d" for Avg (src/FilterDefinitions.C:108-146, 525-544)
+    const int want = op == MRPDR_AVG ? 2 : 1;
+    if (mrpdr_fmt_nfields(st->fmt) != want || mrpdr_fmt_field_kind(st->fmt, 0) != MRPDR_SCALAR ||
+        (op == MRPDR_AVG && mrpdr_fmt_field_type(st->fmt, 1) != MRPDR_INT32_T)) {
+        fprintf(stderr, "ERROR: %s() - invalid packet type: (%s)\n", name, fmt_text);
+        return;
+    }
+    const int type = mrpdr_fmt_field_type(st->fmt, 0);
+    const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, 0);
+    const size_t row = (size_t)mrpdr_fmt_fixed_bytes(st->fmt);
+    if (!grow(st, n, row)) return;
+    // Gather the wave: get_Buffer() is the encoded data of a packet (value[, count], no padding).
+    // A received packet carries its sender's byte order as the last byte of its header
+    // (src/Packet.C:96); a packet made on this node has native order and possibly no header yet.
+    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
+    bool foreign = false;
+    for (size_t i = 0; i < n; i++) {
+        const Packet &p = *in[i];
+        if (strcmp(p.get_FormatString(), fmt_text) != 0 || p.get_BufferLen() != row || !p.get_Buffer()) {
+            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
+            return;
+        }
+        memcpy(st->h_rows + i * row, p.get_Buffer(), row);
+        const char *hdr = p.get_Header();
+        const unsigned hdr_len = p.get_HeaderLen();
+        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
+        foreign = foreign || st->h_orders[i] != native;
+    }
+    if (!hip_ok(hipMemcpyAsync(st->d_rows, st->h_rows, n * row, hipMemcpyHostToDevice, st->stream), "H2D")) return;
+    const void *counts = op == MRPDR_AVG ? st->d_rows + width : NULL;
+    int32_t called;
+    if (foreign) {
+        if (!hip_ok(hipMemcpyAsync(st->d_orders, st->h_orders, n, hipMemcpyHostToDevice, st->stream), "H2D")) return;
+        called = mrpdr_wave_filter_mixed(st->ctx, op, type, MRPDR_SHAPE_FLAT, st->d_rows, row, counts, row, n,
+                                         st->d_orders, st->d_result, st->d_ok, st->stream);
+    } else {
+        called = mrpdr_wave_filter(st->ctx, op, type, MRPDR_SHAPE_FLAT, st->d_rows, row, counts, row, n, 0,
+                                   st->d_result, st->d_ok, st->stream);
+    }
+    if (!called) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
+    uint8_t result[16];
+    int32_t ok = 0;
+    if (!hip_ok(hipMemcpyAsync(result, st->d_result, 16, hipMemcpyDeviceToHost, st->stream), "D2H") ||
+        !hip_ok(hipMemcpyAsync(&ok, st->d_ok, sizeof ok, hipMemcpyDeviceToHost, st->stream), "D2H") ||
+        !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))
+        return;
+    if (!ok) return;            // e.g. an Avg whose counts sum to zero (the reference divides by zero there)
+    // the 16 result bytes are the output packet's fields in order: value, then for Avg the int count
+    const void *fields[2] = { result, result + width };
+    out.push_back(PacketPtr(new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fields, fmt_text)));
+}
+
+} // namespace
+
+extern "C" {
+
+// The loader wants these symbols; MRNet stores the strings and never compares them with a packet
+// (src/Filter.C:35): the functions check the format themselves.
+const char *mrpdr_Sum_format_string = "";
+const char *mrpdr_Min_format_string = "";
+const char *mrpdr_Max_format_string = "";
+const char *mrpdr_Avg_format_string = "";
+
+void mrpdr_Sum(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> & /* out_reverse */,
+               void **state, PacketPtr & /* params */, const TopologyLocalInfo &)
+{
+    run(MRPDR_SUM, "mrpdr_Sum", in, out, state);
+}
+
+void mrpdr_Min(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> &, void **state,
+               PacketPtr &, const TopologyLocalInfo &)
+{
+    run(MRPDR_MIN, "mrpdr_Min", in, out, state);
+}
+
+void mrpdr_Max(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> &, void **state,
+               PacketPtr &, const TopologyLocalInfo &)
+{
+    run(MRPDR_MAX, "mrpdr_Max", in, out, state);
+}
+
+void mrpdr_Avg(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> &, void **state,
+               PacketPtr &, const TopologyLocalInfo &)
+{
+    run(MRPDR_AVG, "mrpdr_Avg", in, out, state);
+}
+
+} // extern "C"
