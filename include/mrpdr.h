@@ -324,6 +324,42 @@ int32_t  mrpdr_message_parse_sizes(mrpdr_ctx *ctx, const uint8_t *sizes, uint64_
                                    uint64_t *buf_offsets, uint64_t *buf_lens,
                                    uint64_t *payload_bytes_host, void *stream);
 
+/* ---- column views: Packet::unpack for a whole wave, without the copies ----------------
+ * The reference hands a tool its data one packet at a time: Packet::unpack(fmt, ...) checks the
+ * format string and then copies -- scalars by value, every array with malloc + memcpy, every string
+ * with strdup, all owned by the caller afterwards (DataElementArray2ArgList, src/Packet.C:1065-1431;
+ * ExtractVaList, src/Packet.C:522-542).  A consumer of whole waves (a filter, a tool's own kernel)
+ * does not need copies: the decoded columns ARE the fields of all packets.  mrpdr_wave_view gives
+ * them out under the same format check, with these rules:
+ *   - a view aliases the columns handed to mrpdr_wave_decode*: values / counts / offs are the
+ *     caller's own device buffers, nothing is allocated, copied or synchronised, nothing needs
+ *     to be freed for the view itself;
+ *   - it describes the wave once the decode calls that were enqueued on `stream` have run: read it
+ *     from work enqueued on the same stream behind them, or after synchronising;
+ *   - it stays valid until the owner of the columns frees them or decodes another wave into them --
+ *     consumers first, columns last; the codec itself keeps no reference to them after a call returns;
+ *   - it is read-only by contract: a filter that wants to change a value makes its own output
+ *     column, as the reference's filters build a new packet.
+ * views: one entry per field.  scalar field: values = T[n]; array / string field: element j of
+ * packet i is values[offs[i] + j], j < counts[i] (strings: bytes, NUL included); string arrays as
+ * in struct mrpdr_column.  Returns FALSE (and fills nothing) when fmt_expected is not the wave's
+ * format string, as unpack returns -1 (src/Packet.C:527-532). */
+typedef struct mrpdr_field_view {
+    const void     *values;
+    const uint64_t *counts;        /* NULL for scalar fields */
+    const uint64_t *offs;          /* NULL for scalar fields; n + 1 entries */
+    const uint64_t *sub_counts;    /* string arrays only */
+    const uint64_t *sub_offs;
+    uint64_t        n;             /* packets */
+    int32_t         type;          /* enum mrpdr_type */
+    int32_t         kind;          /* enum mrpdr_kind */
+    int32_t         width;         /* bytes per element */
+    int32_t         reserved;
+} mrpdr_field_view;
+
+int32_t mrpdr_wave_view(const mrpdr_fmt *f, const char *fmt_expected, const mrpdr_column *cols, uint64_t n,
+                        mrpdr_field_view *views);
+
 /* ---- filters: tfilter_Sum / Min / Max / Avg over a wave ---------------------------
  * (src/FilterDefinitions.C:90-645; arithmetic helpers :1925-2136.)
  * `type` is a scalar DataType.  values = T[n] with a byte stride of value_stride

@@ -20,7 +20,7 @@ SYMBOLS = (
     "mrpdr_fmt_fixed_bytes", "mrpdr_fmt_payload_phase", "mrpdr_fmt_string",
     "mrpdr_wave_sizeof", "mrpdr_wave_encode", "mrpdr_wave_encode_begin", "mrpdr_wave_encode_finish",
     "mrpdr_wave_decode_begin", "mrpdr_wave_decode_finish", "mrpdr_wave_decode",
-    "mrpdr_wave_decode_mixed_begin", "mrpdr_wave_decode_mixed_finish", "mrpdr_wave_decode_mixed",
+    "mrpdr_wave_decode_mixed_begin", "mrpdr_wave_decode_mixed_finish", "mrpdr_wave_decode_mixed", "mrpdr_wave_view",
     "mrpdr_header_bytes", "mrpdr_header_bytes_dest", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
     "mrpdr_wave_filter", "mrpdr_wave_decode_filter", "mrpdr_wave_filter_mixed", "mrpdr_wave_filter_noalloc", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
@@ -33,6 +33,13 @@ class Column(C.Structure):
     _fields_ = [("values", C.c_void_p), ("counts", C.c_void_p), ("offs", C.c_void_p),
                 ("capacity", C.c_uint64), ("sub_counts", C.c_void_p), ("sub_offs", C.c_void_p),
                 ("sub_capacity", C.c_uint64)]
+
+
+class FieldView(C.Structure):
+    """struct mrpdr_field_view"""
+    _fields_ = [("values", C.c_void_p), ("counts", C.c_void_p), ("offs", C.c_void_p),
+                ("sub_counts", C.c_void_p), ("sub_offs", C.c_void_p), ("n", C.c_uint64),
+                ("type", C.c_int32), ("kind", C.c_int32), ("width", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Wire(C.Structure):
@@ -86,6 +93,7 @@ def load():
                                                 C.POINTER(u64), vp]),
         "mrpdr_wave_decode_mixed_finish": (i32, [vp, vp, C.POINTER(Wire), u64, vp, C.POINTER(Column), vp]),
         "mrpdr_wave_decode_mixed": (i32, [vp, vp, C.POINTER(Wire), u64, vp, C.POINTER(Column), vp, vp]),
+        "mrpdr_wave_view": (i32, [vp, C.c_char_p, C.POINTER(Column), u64, C.POINTER(FieldView)]),
         "mrpdr_header_bytes": (u64, [vp]),
         "mrpdr_header_bytes_dest": (u64, [vp, u64]),
         "mrpdr_wave_encode_headers": (i32, [vp, vp, u64, u32, vp, i32, vp, u32, vp, vp, u64, vp, vp, u64, vp]),

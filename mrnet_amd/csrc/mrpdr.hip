@@ -924,6 +924,35 @@ extern "C" int32_t mrpdr_wave_decode_mixed(mrpdr_ctx *c, const mrpdr_fmt *f, con
 }
 
 // ---------------------------------------------------------------------------
+// column views (host-side only: no device work)
+// ---------------------------------------------------------------------------
+extern "C" int32_t mrpdr_wave_view(const mrpdr_fmt *f, const char *fmt_expected, const mrpdr_column *cols, uint64_t n,
+                                   mrpdr_field_view *views)
+{
+    if (!f || !fmt_expected || !views) return fail("mrpdr_wave_view: NULL argument");
+    if (strcmp(fmt_expected, f->text) != 0)           // ExtractVaList, src/Packet.C:527-532
+        return fail("mrpdr_wave_view: format '%s' is not the wave's '%s'", fmt_expected, f->text);
+    if (f->dev.nf && !cols) return fail("mrpdr_wave_view: NULL columns");
+    for (int i = 0; i < f->dev.nf; i++) {
+        const FieldDev &fd = f->dev.f[i];
+        if (n && fd.kind == MRPDR_SCALAR && !cols[i].values) return fail("mrpdr_wave_view: field %d has no values", i);
+        if (n && fd.kind != MRPDR_SCALAR && (!cols[i].counts || !cols[i].offs))
+            return fail("mrpdr_wave_view: field %d has no counts / offs", i);
+    }
+    for (int i = 0; i < f->dev.nf; i++) {
+        const FieldDev &fd = f->dev.f[i];
+        mrpdr_field_view &v = views[i];
+        memset(&v, 0, sizeof v);
+        v.values = cols[i].values;
+        if (fd.kind != MRPDR_SCALAR) { v.counts = cols[i].counts; v.offs = cols[i].offs; }
+        if (fd.kind == MRPDR_STRING_ARRAY) { v.sub_counts = cols[i].sub_counts; v.sub_offs = cols[i].sub_offs; }
+        v.n = n;
+        v.type = fd.type; v.kind = fd.kind; v.width = fd.width;
+    }
+    return 1;
+}
+
+// ---------------------------------------------------------------------------
 // headers
 // ---------------------------------------------------------------------------
 static int32_t make_image(const char *who, const mrpdr_fmt *f, HdrImage *img)

@@ -642,3 +642,4 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     else        tile_copy_fields<false, false, SWAP>(m, img, fmt, tv, wire, cols, np);
 }
 
+

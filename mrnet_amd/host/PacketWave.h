@@ -476,6 +476,21 @@ class PacketWave {
         return 0;
     }
 
+    // Packet::unpack for the whole wave WITHOUT the copies (mrpdr_wave_view): the fields of all
+    // packets as views of the decoded device columns, under unpack's format check (-1 when fmt is
+    // not the wave's format string).  The views alias device memory this PacketWave owns: they are
+    // valid until it is destroyed (consumers first, the wave last), nothing is copied, allocated or
+    // synchronised, and work that reads them goes on context().stream behind the decode.  unpack()
+    // above stays what the reference's unpack is: caller-owned host copies.
+    int view(const char *fmt, std::vector<mrpdr_field_view> &out)
+    {
+        decode_pdr_data();
+        if (!fmt) return -1;
+        out.assign((size_t)mrpdr_fmt_nfields(fmt_), mrpdr_field_view());
+        mrpdr_field_view none;
+        return mrpdr_wave_view(fmt_, fmt, cols_.data(), n_, out.empty() ? &none : out.data()) ? 0 : -1;
+    }
+
     // device views for the filters
     const mrpdr_wire &wire() const { return wire_; }
     const mrpdr_fmt *format() const { return fmt_; }

@@ -157,6 +157,35 @@ class PacketWave:
             return -1
         return self.columns
 
+    def view(self, fmt):
+        """The fields of ALL packets of the wave, in place: what unpack(fmt, ...) hands out one
+        packet and one malloc'ed copy at a time (src/Packet.C:1065-1431), as typed views of the
+        decoded device columns.  -1 when fmt is not the packets' format string (same check as
+        unpack).  Per field: a tensor T[n] for a scalar; (counts[n], offs[n + 1], values) for an
+        array or string field (element j of packet i is values[offs[i] + j]).  Nothing is copied
+        and nothing synchronises: the tensors share the storage of the wave's columns (torch keeps
+        that storage alive as long as a view exists; a C++ or C caller frees consumers first,
+        columns last), and a consumer enqueues its work on the stream the decode ran on."""
+        import ctypes as C
+        from . import capi
+        self._decode()
+        views = (capi.FieldView * max(1, len(self.fmt)))()
+        ok = capi.load().mrpdr_wave_view(self.fmt.handle, None if fmt is None else fmt.encode(),
+                                         W._c_columns(self.columns), self.n, views)
+        if not ok:
+            return -1
+        out = []
+        for i, c in enumerate(self.columns):
+            v = views[i]
+            dt = W.torch_dtype(self.fmt, i)
+            vals = None if c.values is None else c.values.view(torch.uint8).view(dt)
+            assert vals is None or vals.data_ptr() == (v.values or 0)
+            if v.kind == W.SCALAR:
+                out.append(vals[: self.n])
+            else:
+                out.append((c.counts, c.offs, vals))
+        return out
+
     def __getitem__(self, i):
         self._decode()
         return self.columns[i] if 0 <= i < len(self.columns) else None

@@ -130,6 +130,18 @@ class Format:
             pass
 
 
+_TORCH_ELEM = {"c": torch.int8, "uc": torch.uint8, "hd": torch.int16, "uhd": torch.int16, "d": torch.int32,
+               "ud": torch.int32, "ld": torch.int64, "uld": torch.int64, "f": torch.float32, "lf": torch.float64,
+               "s": torch.uint8}
+
+
+def torch_dtype(fmt, i):
+    """Element dtype of field i as a torch view (unsigned wider than 8 bits: the signed dtype of the
+    same width, same bits)."""
+    tok = fmt.tokens[i]
+    return _TORCH_ELEM[tok[1:] if tok[0] in "aA" else tok]
+
+
 def Fmt2Type(token):
     """DataType of one format token, e.g. Fmt2Type('uld') (src/DataElement.C:205-297)."""
     try:

@@ -199,6 +199,52 @@ static void test_filters_default_shape(WaveContext &wc)
     end_SubTest("tfilter_Avg/Sum(default shape = one reference call, 1025 packets)", ok);
 }
 
+// A wave consumer that reads the decoded fields in place (PacketWave::view) instead of taking
+// unpack's copies: here the consumer is the Sum kernel, run straight on the viewed column.
+static void test_column_views(WaveContext &wc)
+{
+    const uint64_t nb = 3000;
+    std::vector<HostColumn> cols(2);
+    std::vector<int32_t> v(nb);
+    std::vector<uint64_t> cnt(nb);
+    std::vector<float> arr;
+    int32_t want = 0;
+    for (uint64_t i = 0; i < nb; i++) {
+        v[i] = (int32_t)(i * 2654435761u);
+        want += v[i];
+        cnt[i] = i % 4;
+        for (uint64_t j = 0; j < cnt[i]; j++) arr.push_back((float)(i + j));
+    }
+    cols[0].set_scalars(v);
+    cols[1].set_arrays(cnt, arr);
+    PacketWave sent(wc, 9, 104, "%d %af", cols, nb);
+    PacketWave *got = received(wc, sent);
+    std::vector<mrpdr_field_view> views;
+    bool ok = got->view("%d %d", views) == -1 && got->view("%d %af", views) == 0 && views.size() == 2;
+    ok = ok && views[0].values == got->columns()[0].values && views[0].n == nb && views[0].type == MRPDR_INT32_T &&
+         views[0].counts == nullptr && views[1].kind == MRPDR_ARRAY && views[1].width == 4 &&
+         views[1].values == got->columns()[1].values && views[1].offs == got->columns()[1].offs;
+    DeviceBuffer d_res, d_ok;
+    d_res.resize(16); d_ok.resize(4);
+    ok = ok && mrpdr_wave_filter(wc.ctx, MRPDR_SUM, views[0].type, MRPDR_SHAPE_FLAT, views[0].values, (uint64_t)views[0].width,
+                                 nullptr, 0, views[0].n, 0, d_res.ptr<void>(), d_ok.ptr<int32_t>(), wc.stream);
+    // the array field's elements, all packets back to back, summed in place as well
+    float fwant = 0.f;
+    for (float x : arr) fwant = fwant + x;
+    DeviceBuffer d_res2;
+    d_res2.resize(16);
+    ok = ok && mrpdr_wave_filter(wc.ctx, MRPDR_SUM, MRPDR_FLOAT_T, MRPDR_SHAPE_FLAT, views[1].values, 4, nullptr, 0,
+                                 got->total(1), 0, d_res2.ptr<void>(), d_ok.ptr<int32_t>(), wc.stream);
+    int32_t sum = 0;
+    float fsum = 0.f;
+    d_res.download(&sum, 4, wc.stream);
+    d_res2.download(&fsum, 4, wc.stream);
+    wc.sync();
+    ok = ok && sum == want && memcmp(&fsum, &fwant, 4) == 0;
+    end_SubTest("PacketWave::view(fields read in place, no host copy)", ok);
+    delete got;                       // consumers are done: now the wave, and with it the columns
+}
+
 static void test_truncated(WaveContext &wc)
 {
     const char *fmt = "%d %ad";
@@ -475,6 +521,7 @@ int main()
         }
         test_filters_known_answers(wc);
         test_filters_default_shape(wc);
+        test_column_views(wc);
         test_truncated(wc);
         test_string_arrays(wc);
         test_builder_reader(wc);

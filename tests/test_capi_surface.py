@@ -125,3 +125,28 @@ def test_group_by_format_host_logic():
     assert sorted(k for k in g if k is not None) == sorted(set(fmts))
     assert g["%d"].tolist() == [0, 2, 5] and g["%af"].tolist() == [3]
     assert g["%d %uld %lf %s %auc"].tolist() == [1, 4] and g[None].tolist() == [6]
+
+
+def test_wave_view_is_host_logic_with_unpack_format_check():
+    """mrpdr_wave_view touches no device: it maps columns to per-field views under the format
+    check of Packet::unpack (src/Packet.C:527-532) -- runs without a GPU."""
+    lib = capi.load()
+    fmt = b"%d %af %s %as"
+    h = lib.mrpdr_fmt_compile(fmt)
+    cols = (capi.Column * 4)()
+    for i in range(4):
+        cols[i] = capi.Column(0x1000 * (i + 1), 0x100 * (i + 1), 0x10 * (i + 1), 5, None, None, 0)
+    cols[0] = capi.Column(0x1000, None, None, 7, None, None, 0)
+    cols[3] = capi.Column(0x4000, 0x400, 0x40, 5, 0x44, 0x48, 3)
+    views = (capi.FieldView * 4)()
+    assert lib.mrpdr_wave_view(h, b"%d %af %s", cols, 7, views) == 0 and "format" in capi.last_error()
+    assert lib.mrpdr_wave_view(h, None, cols, 7, views) == 0
+    assert lib.mrpdr_wave_view(h, fmt, cols, 7, views) == 1
+    assert [v.kind for v in views] == [0, 1, 2, 3] and [v.width for v in views] == [4, 4, 1, 1]
+    assert views[0].values == 0x1000 and views[0].counts is None and views[0].offs is None and views[0].n == 7
+    assert views[1].values == 0x2000 and views[1].counts == 0x200 and views[1].offs == 0x20
+    assert views[3].sub_counts == 0x44 and views[3].sub_offs == 0x48 and views[2].sub_offs is None
+    assert views[1].type == O.fmt_types("%af")[0]
+    bad = (capi.Column * 4)(*[capi.Column(None, None, None, 0, None, None, 0)] * 4)
+    assert lib.mrpdr_wave_view(h, fmt, bad, 7, views) == 0          # columns that hold nothing
+    lib.mrpdr_fmt_free(h)

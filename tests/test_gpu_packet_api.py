@@ -156,6 +156,44 @@ def test_filter_mirrors_default_to_one_reference_call(codec, fmt, n):
         assert out.values(0)[0].tobytes() == np.asarray(ref[0]).tobytes(), (fmt, n, op)
 
 
+def test_wave_view_reads_fields_in_place(codec):
+    """PacketWave.view: the batched, zero-copy form of Packet::unpack (src/Packet.C:1065-1431 is the
+    per-packet malloc + memcpy it removes).  A received wave is decoded once; a second kernel (torch
+    reductions here) reads the field columns in place -- no device-to-host copy, no new device
+    buffer -- under the same format check as unpack; consumers go first, the wave last."""
+    from wavegen import make_wave
+    fmt_s, n = "%d %lf %af %s", 5000
+    ocols = make_wave(fmt_s, n, seed=4, max_count=9)
+    sent = PacketWave(codec, 11, 105, fmt_s, [ocols[0]["values"], ocols[1]["values"],
+                                               (ocols[2]["counts"], ocols[2]["values"]),
+                                               (ocols[3]["counts"], ocols[3]["values"])])
+    got = received(codec, sent)
+    assert got.view("%d %lf") == -1 and got.view(None) == -1            # as unpack: strcmp on the format
+    views = got.view(fmt_s)
+    cols = got.unpack(fmt_s)
+    # in place: the views are the decoded columns' own memory
+    assert views[0].data_ptr() == cols[0].values.data_ptr() and views[0].dtype == torch.int32
+    assert views[1].data_ptr() == cols[1].values.data_ptr() and views[1].dtype == torch.float64
+    counts, offs, vals = views[2]
+    assert vals.data_ptr() == cols[2].values.data_ptr() and vals.dtype == torch.float32
+    assert offs.data_ptr() == cols[2].offs.data_ptr()
+    # a consumer kernel on the device: per-packet array sums by offsets, scalar reductions
+    total = int(offs[n].item())
+    seg = torch.zeros(n, dtype=torch.float64, device=codec.device)
+    owner = torch.repeat_interleave(torch.arange(n, device=codec.device), counts)
+    seg.index_add_(0, owner, vals[:total].to(torch.float64))
+    want = np.zeros(n, np.float64)
+    np.add.at(want, np.repeat(np.arange(n), ocols[2]["counts"].astype(np.int64)), ocols[2]["values"].astype(np.float64))
+    assert np.allclose(seg.cpu().numpy(), want, rtol=1e-12, atol=0)
+    assert int(views[0].sum(dtype=torch.int64).item()) == int(ocols[0]["values"].astype(np.int64).sum())
+    assert float(views[1].max().item()) == float(ocols[1]["values"].max())
+    scnt, soffs, sbytes = views[3]
+    assert sbytes.dtype == torch.uint8 and int(soffs[n].item()) == int(ocols[3]["counts"].sum())
+    assert bytes(sbytes[: int(soffs[n].item())].cpu().numpy()) == ocols[3]["values"].tobytes()
+    del views, counts, offs, vals, scnt, soffs, sbytes              # consumers first ...
+    del got                                                         # ... then the wave
+
+
 def test_receive_side_errors(codec):
     fmt = "%d %ad"
     n = 50
