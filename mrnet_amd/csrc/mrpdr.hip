@@ -754,16 +754,16 @@ static int32_t launch_tile_offs(mrpdr_ctx *c, const mrpdr_fmt *f, const ColsDev 
 }
 
 static int32_t launch_tile_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd, const ColsDev &cd, uint64_t n,
-                                  bool swap, hipStream_t st)
+                                  bool swap, hipStream_t st, const uint8_t *nvalid = nullptr)
 {
     bool timed;
     if (!perf_begin(c, st, &timed, 0)) return 0;
     const bool small = f->tv.nv <= TILE_SMALLV;
     const uint32_t tiles = blocks_for(n, TILE_PKTS);
-    if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
-                else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
-    else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status);
-                else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status); }
+    if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
+                else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid); }
+    else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
+                else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid); }
     LAUNCHED("k_tile_decode");
     return perf_end(c, st, timed, 0);
 }
@@ -890,10 +890,36 @@ extern "C" int32_t mrpdr_wave_decode_finish(mrpdr_ctx *c, const mrpdr_fmt *f, co
     return decode_finish("mrpdr_wave_decode_finish", c, f, wire, n, sender_bo, nullptr, cols, stream);
 }
 
+// Waves of short packets decoded by ONE call: the first pass reads only the length prefixes
+// (k_count_walk), the payload kernel writes the scalar columns as well -- the wire is read once.
+// Returns -1 when the wave is not of that kind (the caller takes begin + finish).
+static int32_t decode_short_packets(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire, uint64_t n,
+                                    int32_t sender_bo, mrpdr_column *cols, int32_t *ok, void *stream)
+{
+    if (!c || !f || !wire || !cols || f->fixed || n == 0 || n > c->max_packets || f->dev.nf > 255) return -1;
+    if (sender_bo != MRPDR_LITTLEENDIAN && sender_bo != MRPDR_BIGENDIAN) return -1;
+    if (!check_common(who, c, f, n)) return 0;
+    ColsDev cd;
+    WireDev wd;
+    if (!fill_cols(who, f, cols, n, true, &cd)) return 0;
+    if (!fill_wire(who, f, wire, n, &wd)) return 0;
+    if (!tile_path_ok(f, wd, n)) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
+    uint8_t *nvalid = (uint8_t *)c->pkt_bytes;             // one byte per packet of the ctx workspace
+    if (swap) k_count_walk<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
+    else      k_count_walk<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
+    LAUNCHED("k_count_walk");
+    if (!launch_tile_offs(c, f, cd, n, st)) return 0;
+    return launch_tile_decode(c, f, wd, cd, n, swap, st, nvalid);
+}
+
 extern "C" int32_t mrpdr_wave_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const mrpdr_wire *wire,
                                      uint64_t n, int32_t sender_bo, mrpdr_column *cols,
                                      int32_t *ok, void *stream)
 {
+    const int32_t one = decode_short_packets("mrpdr_wave_decode", c, f, wire, n, sender_bo, cols, ok, stream);
+    if (one >= 0) return one;
     if (!decode_begin("mrpdr_wave_decode", c, f, wire, n, sender_bo, nullptr, cols, ok, nullptr, stream)) return 0;
     return decode_finish("mrpdr_wave_decode", c, f, wire, n, sender_bo, nullptr, cols, stream);
 }

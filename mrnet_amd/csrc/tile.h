@@ -567,6 +567,70 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv
 }
 
 // ---------------------------------------------------------------------------
+// decode in one call: the counts without the wire image
+// ---------------------------------------------------------------------------
+// When one call decodes the whole wave, nobody needs the scalar columns before the payloads move:
+// the payload kernel has every packet in LDS anyway and writes the scalars from there.  What has to
+// be known beforehand is only what offs[] is made of -- the length prefixes.  So the first pass does
+// not stage anything: one lane per packet reads the packet's prefixes straight from the arena
+// (one dependent load per variable field; the bounds of everything in between are arithmetic on
+// lengths, the same tests as walk_decode_packet) and leaves counts[], ok[], how many leading
+// fields of the packet are good, and the per-tile sums.  It touches the cache lines that hold a
+// prefix instead of the whole wire, and a CU runs 2,048 such lanes at once instead of five
+// wavefronts walking LDS images.
+template <bool SWAP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_count_walk(FmtDev fmt, WireDev wire, ColsDev cols,
+                                                          uint64_t n, int32_t *ok, uint8_t *nvalid,
+                                                          uint64_t *tile_sums, uint64_t ntiles)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint64_t tile = i / TILE_PKTS;                  // one wavefront = one tile
+    const bool live = i < n;
+    uint64_t at = 0, space = 0;
+    if (live) { at = wire.offsets[i]; space = wire.lens[i]; }
+    bool good = live && at <= wire.bytes && space <= wire.bytes - at;
+    const uint8_t *p = wire.base + at;
+    uint32_t valid = 0;
+    int v = 0;
+    for (int f = 0; f < fmt.nf; f++) {
+        const FieldDev fd = fmt.f[f];
+        const uint32_t w = fd.width;
+        if (fd.kind == MRPDR_SCALAR) {
+            if (good && w <= space) { p += w; space -= w; valid++; }
+            else good = false;
+            continue;
+        }
+        uint64_t cnt = 0;
+        if (fd.kind == MRPDR_ARRAY) {
+            if (good && 8 <= space) {
+                cnt = ld_wire<8>(p, SWAP); p += 8; space -= 8;
+                const uint64_t bound = fd.large ? UINT64_MAX : (uint64_t)INT32_MAX;
+                if (cnt > bound || cnt > (space >> __builtin_ctz(w))) { good = false; cnt = 0; }
+                else valid++;
+                p += cnt * w; space -= cnt * w;
+            } else good = false;
+        } else {                                          // MRPDR_STRING: u32 strlen+1, then the bytes
+            if (good && 4 <= space) {
+                cnt = ld_wire<4>(p, SWAP); p += 4; space -= 4;
+                if (cnt == 0 || cnt > space) { good = false; cnt = 0; }
+                else valid++;
+                p += cnt; space -= cnt;
+            } else good = false;
+        }
+        if (live) cols.counts[f][i] = cnt;
+        uint64_t c = cnt;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor((unsigned long long)c, d, 64);
+        if ((threadIdx.x & 63u) == 0 && tile < ntiles && tile * TILE_PKTS < n) tile_sums[(uint64_t)v * ntiles + tile] = c;
+        v++;
+    }
+    if (live) {
+        if (ok) ok[i] = good ? 1 : 0;
+        nvalid[i] = (uint8_t)valid;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // decode, begin: offsets of every variable field, one launch
 // ---------------------------------------------------------------------------
 // Workgroup (c, v) owns TILE_OFFS_PKTS packets of variable field v.  Its base is the sum of the
@@ -606,9 +670,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev co
 // ---------------------------------------------------------------------------
 // decode, finish: payloads
 // ---------------------------------------------------------------------------
+// nvalid (optional): the one-call decode -- the scalar columns are written here too, from the
+// image, with k_count_walk's verdict on every packet (field f of packet i is good iff f < nvalid[i];
+// the fields behind a failure read as zero).
 template <bool SWAP, int V>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
-                                                           uint64_t n, uint32_t *status)
+                                                           uint64_t n, uint32_t *status, const uint8_t *nvalid)
 {
     __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
@@ -618,10 +685,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     // a column too small for the wave, or offs[] that do not describe these packets: nothing is
     // written, the status word says so
     tile_load_meta<true, true>(m, tv, wire, cols, p0, np, n);
-    if (m.too_small) {
-        if (t == 0) atomicOr(status, 1u);
-        return;
-    }
+    const bool skip = m.too_small != 0;          // no payload moves (the scalar columns are still written)
+    if (skip && t == 0) atomicOr(status, 1u);
+    if (skip && !nvalid) return;
     const bool staged = m.staged != 0;
     if (staged) {
         const uint64_t lo = m.start[0];
@@ -638,6 +704,29 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
         }
     }
     __syncthreads();
+    if (nvalid) {
+        // scalars: one wavefront per field, one lane per packet (the field's width and column
+        // come from scalar loads, the column stores of a wavefront are one contiguous run)
+        const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+        const uint32_t i = t & 63u;
+        const uint64_t lo = m.start[0];
+        const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+        const uint32_t good_fields = i < np ? nvalid[p0 + i] : 0u;
+        for (int f = wv; f < fmt.nf; f += MRPDR_TPB / 64) {
+            const FieldDev fd = fmt.f[f];
+            if (fd.kind != MRPDR_SCALAR || i >= np) continue;
+            uint64_t x = 0;
+            const uint64_t pos = fd.fixed_before + tile_var_before(m, tv, fmt, f, i);
+            // (the place is checked against the packet once more: offs[] may be anything when the
+            // payloads are being skipped)
+            if ((uint32_t)f < good_fields && m.end[i] >= m.start[i] && pos + fd.width <= m.end[i] - m.start[i]) {
+                const uint64_t at = m.start[i] + pos;
+                x = ld_wire_w(staged ? tile_at<true>(img, wire.base, lo, mis, at) : wire.base + at, (int)fd.width, SWAP);
+            }
+            st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + (p0 + i) * fd.width, (int)fd.width, x);
+        }
+    }
+    if (skip) return;
     if (staged) tile_copy_fields<true, false, SWAP>(m, img, fmt, tv, wire, cols, np);
     else        tile_copy_fields<false, false, SWAP>(m, img, fmt, tv, wire, cols, np);
 }
