@@ -745,10 +745,11 @@ static int32_t launch_tile_walk(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev 
     return 1;
 }
 
-static int32_t launch_tile_offs(mrpdr_ctx *c, const mrpdr_fmt *f, const ColsDev &cd, uint64_t n, hipStream_t st)
+static int32_t launch_tile_offs(mrpdr_ctx *c, const mrpdr_fmt *f, const ColsDev &cd, uint64_t n, uint32_t pkts_per_sum,
+                                hipStream_t st)
 {
     k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt,
-                                                                                                 c->ntile_cnt);
+                                                                                                 c->ntile_cnt, pkts_per_sum);
     LAUNCHED("k_tile_offs");
     return 1;
 }
@@ -803,7 +804,7 @@ static int32_t decode_begin(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, c
             LAUNCHED("k_rows_decode");
         } else if (!orders && tile_path_ok(f, wd, n)) {
             if (!launch_tile_walk(c, f, wd, cd, n, swap, ok, st)) return 0;
-            if (!launch_tile_offs(c, f, cd, n, st)) return 0;
+            if (!launch_tile_offs(c, f, cd, n, TILE_PKTS, st)) return 0;
             for (int i = 0; totals_host && i < f->dev.nf; i++)
                 if (f->dev.f[i].kind != MRPDR_SCALAR)
                     HIP_OK(hipMemcpyAsync(&totals_host[i], cd.offs[i] + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
@@ -907,10 +908,10 @@ static int32_t decode_short_packets(const char *who, mrpdr_ctx *c, const mrpdr_f
     hipStream_t st = (hipStream_t)stream;
     const bool swap = sender_bo != MRPDR_LITTLEENDIAN;
     uint8_t *nvalid = (uint8_t *)c->pkt_bytes;             // one byte per packet of the ctx workspace
-    if (swap) k_count_walk<true><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
-    else      k_count_walk<false><<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
+    if (swap) k_count_walk<true><<<blocks_for(n, COUNT_WALK_TPB), COUNT_WALK_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
+    else      k_count_walk<false><<<blocks_for(n, COUNT_WALK_TPB), COUNT_WALK_TPB, 0, st>>>(f->dev, wd, cd, n, ok, nvalid, c->tile_cnt, c->ntile_cnt);
     LAUNCHED("k_count_walk");
-    if (!launch_tile_offs(c, f, cd, n, st)) return 0;
+    if (!launch_tile_offs(c, f, cd, n, COUNT_WALK_TPB, st)) return 0;
     return launch_tile_decode(c, f, wd, cd, n, swap, st, nvalid);
 }
 

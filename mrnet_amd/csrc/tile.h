@@ -578,13 +578,15 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv
 // fields of the packet are good, and the per-tile sums.  It touches the cache lines that hold a
 // prefix instead of the whole wire, and a CU runs 2,048 such lanes at once instead of five
 // wavefronts walking LDS images.
+#define COUNT_WALK_TPB TILE_OFFS_PKTS       // one workgroup = the packets of one k_tile_offs workgroup
+
 template <bool SWAP>
-__global__ __launch_bounds__(MRPDR_TPB) void k_count_walk(FmtDev fmt, WireDev wire, ColsDev cols,
-                                                          uint64_t n, int32_t *ok, uint8_t *nvalid,
-                                                          uint64_t *tile_sums, uint64_t ntiles)
+__global__ __launch_bounds__(COUNT_WALK_TPB) void k_count_walk(FmtDev fmt, WireDev wire, ColsDev cols,
+                                                               uint64_t n, int32_t *ok, uint8_t *nvalid,
+                                                               uint64_t *block_sums, uint64_t stride)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    const uint64_t tile = i / TILE_PKTS;                  // one wavefront = one tile
+    __shared__ uint64_t s_part[COUNT_WALK_TPB / 64];
+    const uint64_t i = (uint64_t)blockIdx.x * COUNT_WALK_TPB + threadIdx.x;
     const bool live = i < n;
     uint64_t at = 0, space = 0;
     if (live) { at = wire.offsets[i]; space = wire.lens[i]; }
@@ -618,10 +620,18 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_count_walk(FmtDev fmt, WireDev wi
             } else good = false;
         }
         if (live) cols.counts[f][i] = cnt;
+        // the workgroup's total of this field
         uint64_t c = cnt;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) c += __shfl_xor((unsigned long long)c, d, 64);
-        if ((threadIdx.x & 63u) == 0 && tile < ntiles && tile * TILE_PKTS < n) tile_sums[(uint64_t)v * ntiles + tile] = c;
+        __syncthreads();                                  // s_part is free again
+        if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t total = 0;
+            for (int k = 0; k < COUNT_WALK_TPB / 64; k++) total += s_part[k];
+            block_sums[(uint64_t)v * stride + blockIdx.x] = total;
+        }
         v++;
     }
     if (live) {
@@ -634,18 +644,20 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_count_walk(FmtDev fmt, WireDev wi
 // decode, begin: offsets of every variable field, one launch
 // ---------------------------------------------------------------------------
 // Workgroup (c, v) owns TILE_OFFS_PKTS packets of variable field v.  Its base is the sum of the
-// tile sums in front of it (read in parallel; a wave of 2^21 packets has 32,768 of them), then
-// a workgroup scan of its own counts.
+// partial sums in front of it (read in parallel), then a workgroup scan of its own counts.  The
+// partial sums cover pkts_per_sum packets each: a tile (k_tile_walk), or as many packets as this
+// kernel's workgroups own (k_count_walk) -- then workgroup c simply adds up the c sums before it,
+// 1,024 values at most on a wave of 2^20 packets.
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev cols, uint64_t n,
-                                                         const uint64_t *tile_sums, uint64_t ntiles)
+                                                         const uint64_t *part_sums, uint64_t stride, uint32_t pkts_per_sum)
 {
     const int v = blockIdx.y;
     const int f = tv.field[v];
     const uint64_t first = (uint64_t)blockIdx.x * TILE_OFFS_PKTS;
-    const uint64_t tiles_before = first / TILE_PKTS;
-    const uint64_t *sums = tile_sums + (uint64_t)v * ntiles;
+    const uint64_t sums_before = first / pkts_per_sum;
+    const uint64_t *sums = part_sums + (uint64_t)v * stride;
     uint64_t s = 0;
-    for (uint64_t j = threadIdx.x; j < tiles_before; j += MRPDR_TPB) s += sums[j];
+    for (uint64_t j = threadIdx.x; j < sums_before; j += MRPDR_TPB) s += sums[j];
     uint64_t base;
     block_exclusive_scan(s, &base);
     constexpr int IPT = TILE_OFFS_PKTS / MRPDR_TPB;
@@ -682,6 +694,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
+    // (lane i of every wavefront: how many leading fields of packet i are good -- loaded with the
+    // boundaries, not when the scalars need it)
+    const uint32_t good_fields = (nvalid && (t & 63u) < np) ? nvalid[p0 + (t & 63u)] : 0u;
     // a column too small for the wave, or offs[] that do not describe these packets: nothing is
     // written, the status word says so
     tile_load_meta<true, true>(m, tv, wire, cols, p0, np, n);
@@ -711,7 +726,6 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
         const uint32_t i = t & 63u;
         const uint64_t lo = m.start[0];
         const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
-        const uint32_t good_fields = i < np ? nvalid[p0 + i] : 0u;
         for (int f = wv; f < fmt.nf; f += MRPDR_TPB / 64) {
             const FieldDev fd = fmt.f[f];
             if (fd.kind != MRPDR_SCALAR || i >= np) continue;
@@ -721,7 +735,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
             // payloads are being skipped)
             if ((uint32_t)f < good_fields && m.end[i] >= m.start[i] && pos + fd.width <= m.end[i] - m.start[i]) {
                 const uint64_t at = m.start[i] + pos;
-                x = ld_wire_w(staged ? tile_at<true>(img, wire.base, lo, mis, at) : wire.base + at, (int)fd.width, SWAP);
+                // (two branches, not one pointer chosen between LDS and the arena: that would be a flat access)
+                if (staged) x = ld_wire_w(img + (uint32_t)(at - lo) + mis, (int)fd.width, SWAP);
+                else        x = ld_wire_w(wire.base + at, (int)fd.width, SWAP);
             }
             st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + (p0 + i) * fd.width, (int)fd.width, x);
         }

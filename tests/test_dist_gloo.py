@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from wavegen import O, random_values
+from wavegen import O, ROOT, random_values
 
 from mrnet_amd import dist as D
 from mrnet_amd import wave as W
@@ -145,3 +145,20 @@ def test_two_ranks_perfdata_exchange():
                               (lens.astype(np.uint64), data.view(np.float64)[:2 * k]))
     tree = O.filter_perfdata_tree(O.AVG, O.DOUBLE_T, (rc, rv), (dc, dv), [n // 2, 0])
     assert final[0] == tree[0] == -n and np.array_equal(final[1].view(np.uint8), tree[1].view(np.uint8))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it starts N rank processes itself
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set) before anything touches a GPU.  Here, without a
+    GPU, every rank must come up, say that it needs a HIP device, and the parent must hand their
+    failure on as its own exit code."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the GPU test of the same command")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert r.stderr.count("needs a HIP device") == 3, r.stderr[-2000:]

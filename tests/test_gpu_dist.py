@@ -78,3 +78,50 @@ def test_two_ranks_on_one_gpu():
         assert int(res[8:12].view(np.int32)[0]) == int(want[1]) == int(cnts.sum())
         assert plen == K and prank == tree[0] == -N
         assert pd.view(np.float64)[:K].tobytes() == tree[1].tobytes()
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    try:
+        codec = W.Codec(device=rank, max_packets=1 << 16)
+        lo, hi = D.shard_range(N, rank, world)
+        vals, cnts = _scalar_wave(N)
+        rows = np.zeros((hi - lo, 12), np.uint8)
+        rows[:, :8] = vals[lo:hi].view(np.uint8).reshape(-1, 8)
+        rows[:, 8:] = cnts[lo:hi].view(np.uint8).reshape(-1, 4)
+        wire = W.WireWave(codec.to_device(rows.reshape(-1)), hi - lo, None, None, 12)
+        res, ok = D.filter_wire_sharded(codec, W.TFILTER_AVG, W.Format("%lf %d"), wire)    # all_gather over RCCL
+        torch.cuda.synchronize()
+        q.put((rank, res.cpu().numpy().copy(), int(ok.item())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_over_rccl():
+    """The same exchange with the real backend: one rank per GPU, the 20-byte results gathered by
+    RCCL on the device.  Needs two GPUs (the single-GPU box skips it; the two-ranks-one-GPU test
+    above covers the path with gloo)."""
+    world = 2
+    if torch.cuda.device_count() < world:
+        pytest.skip("needs %d GPUs" % world)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    vals, cnts = _scalar_wave(N)
+    parts = [O.filter_tree(O.AVG, O.DOUBLE_T, vals[lo:hi], cnts[lo:hi], W.TREE_FANINS)
+             for lo, hi in (D.shard_range(N, r, world) for r in range(world))]
+    want = O.filter_flat(O.AVG, O.DOUBLE_T, np.array([p[0] for p in parts]), np.array([p[1] for p in parts], np.int32))
+    for rank, res, ok in got:
+        assert ok == 1 and res[:8].tobytes() == np.float64(want[0]).tobytes()
+        assert int(res[8:12].view(np.int32)[0]) == int(want[1])
