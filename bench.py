@@ -455,13 +455,18 @@ def message_extra(codec):
         def parse():
             _, hdr, wire = codec.message_parse(fmt, msg)
             codec.decode(fmt, wire)
-        tb, tp = time_call(build, 30), time_call(parse, 30)
+
+        def parse_known_count():        # the receiver read the count and the length off the socket itself
+            _, hdr, wire = codec.message_parse(fmt, msg, n=n, check_length=False)
+            codec.decode(fmt, wire)
+        tb, tp, tk = time_call(build, 30), time_call(parse, 30), time_call(parse_known_count, 30)
         _, hdr, wire = codec.message_parse(fmt, msg)
         dcols, ok = codec.decode(fmt, wire)
         assert bool(ok.all()) and bool(hdr["ok"].all())
         assert torch.equal(dcols[0].values.view(torch.uint8), cols[0].values.view(torch.uint8))
         out["f1_%s_message_build_us" % name] = round(tb * 1e6, 1)
         out["f1_%s_message_parse_decode_us" % name] = round(tp * 1e6, 1)
+        out["f1_%s_message_parse_decode_known_count_us" % name] = round(tk * 1e6, 1)
         out["f1_%s_message_mib" % name] = round(msg.numel() / 2**20, 1)
     return out
 

@@ -506,23 +506,34 @@ class Codec:
                             out=msg, out_ptr=msg.data_ptr() + pre - h, offsets=offsets)
         return msg
 
-    def message_parse(self, fmt, msg):
-        """Message -> (header fields, WireWave of the data buffers).  The 5-byte count is read on
-        the host, as Message::recv does before it knows how much more to receive."""
-        head = msg[:5].cpu().numpy()
-        bo = int(head[0])
-        n = int(head[1:5].view(">u4" if bo == BIGENDIAN else "<u4")[0])
+    def message_parse(self, fmt, msg, n=None, check_length=True):
+        """Message -> (n, header fields, WireWave of the data buffers).  Message::recv reads the
+        5-byte count from the socket before it knows how much more to receive (src/Message.C:71-86),
+        so a caller that received the message itself passes that count as `n`; without it the
+        count is read back from the device buffer here (one synchronisation).  check_length=False
+        skips the host-side comparison of the size vector's total with the buffer length (another
+        synchronisation): headers and data buffers that do not lie inside the buffer then simply
+        fail as packets (ok = 0), nothing outside the buffer is touched."""
+        if n is None:
+            head = msg[:5].cpu().numpy()
+            bo = int(head[0])
+            n = int(head[1:5].view(">u4" if bo == BIGENDIAN else "<u4")[0])
         pre = int(self._lib.mrpdr_message_preamble_bytes(n))
+        if pre > msg.numel():
+            raise PdrError("message shorter than its size vector")
         hdr_offs, buf_offs = self.empty(n + 1, torch.int64), self.empty(n + 1, torch.int64)
         hdr_lens, buf_lens = self.empty(n, torch.int64), self.empty(n, torch.int64)
         total = C.c_uint64(0)
         r = self._lib.mrpdr_message_parse_sizes(self.handle, msg.data_ptr() + 5, n, _ptr(hdr_offs),
                                                 _ptr(hdr_lens), _ptr(buf_offs), _ptr(buf_lens),
-                                                C.byref(total), _stream())
+                                                C.byref(total) if check_length else None, _stream())
         _check(r, "mrpdr_message_parse_sizes")
-        if pre + total.value > msg.numel():
-            raise PdrError("message shorter than its size vector announces")
-        payload = msg[pre:pre + total.value]
+        if check_length:
+            if pre + total.value > msg.numel():
+                raise PdrError("message shorter than its size vector announces")
+            payload = msg[pre:pre + total.value]
+        else:
+            payload = msg[pre:]
         hdr = self.decode_headers(fmt, n, payload, offsets=hdr_offs, lens=hdr_lens)
         return n, hdr, WireWave(payload, n, buf_offs, buf_lens, 0)
 

@@ -142,6 +142,22 @@ def test_untrusted_sizes_cannot_reach_memory(codec):
         codec.message_parse(fmt, codec.to_device(bad))
     nn, hd, wire = codec.message_parse(fmt, msg)
     assert nn == n and bool(hd["ok"].all())
+    # the same without the host-side length check (the receiver knows the count from the socket):
+    # nothing is refused up front, the packets that do not lie inside the buffer fail one by one
+    nn, hd, wire = codec.message_parse(fmt, msg, n=n, check_length=False)
+    dcols, dok = codec.decode(fmt, wire)
+    assert bool(hd["ok"].all()) and bool(dok.all())
+    assert np.array_equal(W.Codec.to_numpy(dcols[0].values).view(np.int32)[:n], vals)
+    for at, val in ((5 + 16 * 2, 2**64 - 1), (5 + 16 * 3 + 8, 2**63 + 5), (5, 2**62)):
+        bad = good.copy()
+        bad[at:at + 8] = np.frombuffer(int(val).to_bytes(8, "little"), np.uint8)
+        nn, hd, wire = codec.message_parse(fmt, codec.to_device(bad), n=n, check_length=False)
+        dcols, dok = codec.decode(fmt, wire)
+        torch.cuda.synchronize()
+        first_bad = (at - 5) // 16
+        hok, dk = W.Codec.to_numpy(hd["ok"]), W.Codec.to_numpy(dok)
+        assert hok[:first_bad].all() and dk[:first_bad].all()          # the packets in front are intact
+        assert not (hok[first_bad:].all() and dk[first_bad:].all())
     # n * stride wraps around 2^64
     arena = torch.zeros(64, dtype=torch.uint8, device=codec.device)
     col = (capi.Column * 1)()
