@@ -578,14 +578,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv
 // fields of the packet are good, and the per-tile sums.  It touches the cache lines that hold a
 // prefix instead of the whole wire, and a CU runs 2,048 such lanes at once instead of five
 // wavefronts walking LDS images.
-#define COUNT_WALK_TPB TILE_OFFS_PKTS       // one workgroup = the packets of one k_tile_offs workgroup
+#define COUNT_WALK_TPB 256                  // packets per workgroup, and per partial sum
 
 template <bool SWAP>
 __global__ __launch_bounds__(COUNT_WALK_TPB) void k_count_walk(FmtDev fmt, WireDev wire, ColsDev cols,
                                                                uint64_t n, int32_t *ok, uint8_t *nvalid,
                                                                uint64_t *block_sums, uint64_t stride)
 {
-    __shared__ uint64_t s_part[COUNT_WALK_TPB / 64];
+    __shared__ uint64_t s_part[TILE_MAXV][COUNT_WALK_TPB / 64];
     const uint64_t i = (uint64_t)blockIdx.x * COUNT_WALK_TPB + threadIdx.x;
     const bool live = i < n;
     uint64_t at = 0, space = 0;
@@ -594,6 +594,7 @@ __global__ __launch_bounds__(COUNT_WALK_TPB) void k_count_walk(FmtDev fmt, WireD
     const uint8_t *p = wire.base + at;
     uint32_t valid = 0;
     int v = 0;
+    // (no barrier inside the walk: a wavefront's dependent loads wait for nobody else's)
     for (int f = 0; f < fmt.nf; f++) {
         const FieldDev fd = fmt.f[f];
         const uint32_t w = fd.width;
@@ -620,23 +621,22 @@ __global__ __launch_bounds__(COUNT_WALK_TPB) void k_count_walk(FmtDev fmt, WireD
             } else good = false;
         }
         if (live) cols.counts[f][i] = cnt;
-        // the workgroup's total of this field
+        // the wavefront's total of this field
         uint64_t c = cnt;
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) c += __shfl_xor((unsigned long long)c, d, 64);
-        __syncthreads();                                  // s_part is free again
-        if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6] = c;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t total = 0;
-            for (int k = 0; k < COUNT_WALK_TPB / 64; k++) total += s_part[k];
-            block_sums[(uint64_t)v * stride + blockIdx.x] = total;
-        }
+        if ((threadIdx.x & 63u) == 0) s_part[v][threadIdx.x >> 6] = c;
         v++;
     }
     if (live) {
         if (ok) ok[i] = good ? 1 : 0;
         nvalid[i] = (uint8_t)valid;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < v) {
+        uint64_t total = 0;
+        for (int k = 0; k < COUNT_WALK_TPB / 64; k++) total += s_part[threadIdx.x][k];
+        block_sums[(uint64_t)threadIdx.x * stride + blockIdx.x] = total;
     }
 }
 
@@ -645,9 +645,9 @@ __global__ __launch_bounds__(COUNT_WALK_TPB) void k_count_walk(FmtDev fmt, WireD
 // ---------------------------------------------------------------------------
 // Workgroup (c, v) owns TILE_OFFS_PKTS packets of variable field v.  Its base is the sum of the
 // partial sums in front of it (read in parallel), then a workgroup scan of its own counts.  The
-// partial sums cover pkts_per_sum packets each: a tile (k_tile_walk), or as many packets as this
-// kernel's workgroups own (k_count_walk) -- then workgroup c simply adds up the c sums before it,
-// 1,024 values at most on a wave of 2^20 packets.
+// partial sums cover pkts_per_sum packets each: a tile (k_tile_walk) or a workgroup of
+// k_count_walk; workgroup c adds up the sums in front of its first packet (4,096 values at most
+// on a wave of 2^20 packets, sixteen per lane).
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev cols, uint64_t n,
                                                          const uint64_t *part_sums, uint64_t stride, uint32_t pkts_per_sum)
 {
