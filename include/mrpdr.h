@@ -324,6 +324,37 @@ int32_t  mrpdr_message_parse_sizes(mrpdr_ctx *ctx, const uint8_t *sizes, uint64_
                                    uint64_t *buf_offsets, uint64_t *buf_lens,
                                    uint64_t *payload_bytes_host, void *stream);
 
+/* The framing of both directions as one call each (no host synchronisation in either).
+ *
+ * mrpdr_message_write_frame = mrpdr_message_write_preamble + mrpdr_wave_encode_headers for a wave
+ * without destination lists, in one launch: what Message::send adds around the data buffers
+ * (src/Message.C:201-335 over the header buffers of Packet::encode_pdr_header, src/Packet.C:557-593).
+ * lens / offsets are mrpdr_wave_sizeof's (align 1, phase = mrpdr_header_bytes(f)); msg is the whole
+ * message buffer, mrpdr_message_preamble_bytes(n) + offsets[n] bytes; stream_ids / tags / src_ranks
+ * as in mrpdr_wave_encode_headers.
+ *
+ * mrpdr_message_parse = mrpdr_message_parse_sizes + mrpdr_wave_decode_headers in two launches: what
+ * Message::recv does with a received message before the packets' data is looked at
+ * (src/Message.C:48-199, which builds a Packet from every header buffer: Packet::decode_pdr_header,
+ * src/Packet.C:87-104).  msg / msg_bytes: the whole message as received; n: its packet count (the
+ * receiver read the 5-byte count off the link before it could receive the rest, src/Message.C:71-86).
+ * Offsets are relative to the payload, msg + mrpdr_message_preamble_bytes(n); [n] of both offset
+ * arrays is the payload size the size vector announces.  Sizes are untrusted: a header or data
+ * buffer that does not lie inside msg fails as a packet (hdr_ok[i] = 0, ok[i] = 0 from the decode),
+ * nothing outside msg is read.  Header outputs as in mrpdr_wave_decode_headers (any may be NULL). */
+int32_t  mrpdr_message_write_frame(mrpdr_ctx *ctx, const mrpdr_fmt *f, uint64_t n,
+                                   const uint64_t *lens, const uint64_t *offsets,
+                                   uint32_t stream_id, const uint32_t *stream_ids,
+                                   int32_t tag, const int32_t *tags,
+                                   uint32_t src_rank, const uint32_t *src_ranks,
+                                   uint8_t *msg, void *stream);
+int32_t  mrpdr_message_parse(mrpdr_ctx *ctx, const mrpdr_fmt *f, const uint8_t *msg, uint64_t msg_bytes,
+                             uint64_t n, uint64_t *hdr_offsets, uint64_t *hdr_lens,
+                             uint64_t *buf_offsets, uint64_t *buf_lens,
+                             uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
+                             uint8_t *byteorders, uint64_t *ndests,
+                             uint32_t *dest_ranks, uint64_t dest_stride, int32_t *hdr_ok, void *stream);
+
 /* ---- column views: Packet::unpack for a whole wave, without the copies ----------------
  * The reference hands a tool its data one packet at a time: Packet::unpack(fmt, ...) checks the
  * format string and then copies -- scalars by value, every array with malloc + memcpy, every string

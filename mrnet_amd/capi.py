@@ -23,6 +23,7 @@ SYMBOLS = (
     "mrpdr_wave_decode_mixed_begin", "mrpdr_wave_decode_mixed_finish", "mrpdr_wave_decode_mixed", "mrpdr_wave_view",
     "mrpdr_header_bytes", "mrpdr_header_bytes_dest", "mrpdr_wave_encode_headers", "mrpdr_wave_decode_headers",
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
+    "mrpdr_message_write_frame", "mrpdr_message_parse",
     "mrpdr_wave_filter", "mrpdr_wave_decode_filter", "mrpdr_wave_filter_mixed", "mrpdr_wave_filter_noalloc", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
     "mrpdr_eqclass_scratch_bytes", "mrpdr_wave_int_eq_class",
 )
@@ -100,6 +101,8 @@ def load():
         "mrpdr_message_preamble_bytes": (u64, [u64]),
         "mrpdr_message_write_preamble": (i32, [vp, u64, u64, vp, vp, vp]),
         "mrpdr_message_parse_sizes": (i32, [vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64), vp]),
+        "mrpdr_message_write_frame": (i32, [vp, vp, u64, vp, vp, u32, vp, i32, vp, u32, vp, vp, vp]),
+        "mrpdr_message_parse": (i32, [vp, vp, vp, u64, u64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "mrpdr_wave_decode_headers": (i32, [vp, vp, u64, vp, u64, vp, vp, u64, vp, vp, vp, vp, vp, vp, u64, vp, vp]),
         "mrpdr_wave_filter": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
         "mrpdr_wave_filter_mixed": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, vp, vp, vp, vp]),

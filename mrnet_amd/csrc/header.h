@@ -22,23 +22,6 @@ struct HdrEncodeArgs {
     uint8_t *hdrs; const uint64_t *hdr_offsets; uint64_t hdr_stride; uint64_t n;
 };
 
-__global__ __launch_bounds__(MRPDR_TPB) void k_hdr_encode(HdrEncodeArgs a, HdrImage img)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= a.n) return;
-    uint8_t *p = a.hdrs + (a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride);
-    st_u<uint32_t>(p + 0, a.stream_ids ? a.stream_ids[i] : a.stream_id);
-    st_u<int32_t>(p + 4, a.tags ? a.tags[i] : a.tag);
-    st_u<uint32_t>(p + 8, a.src_ranks ? a.src_ranks[i] : a.src_rank);
-    st_u<uint32_t>(p + 12, img.fmt_bytes);
-    for (uint32_t b = 0; b < img.fmt_bytes; b++) p[16 + b] = img.fmt[b];
-    uint8_t *q = p + 16 + img.fmt_bytes;
-    st_u<uint64_t>(q, a.ndest);                 // pdr_uint64(dest count), src/Packet.C:579-585
-    q += 8;
-    for (uint64_t d = 0; d < a.ndest; d++, q += 4) st_u<uint32_t>(q, a.dests[d]);
-    q[0] = (uint8_t)MRPDR_LITTLEENDIAN;         // pdrmem_getbo() of this device
-}
-
 struct HdrDecodeArgs {
     const uint8_t *hdrs; uint64_t hdrs_bytes; const uint64_t *hdr_offsets; const uint64_t *hdr_lens; uint64_t hdr_stride;
     uint32_t *stream_ids; int32_t *tags; uint32_t *src_ranks; uint8_t *byteorders; uint64_t *ndests;
@@ -46,14 +29,11 @@ struct HdrDecodeArgs {
     int32_t *ok; uint64_t n;
 };
 
-__global__ __launch_bounds__(MRPDR_TPB) void k_hdr_decode(HdrDecodeArgs a, HdrImage img)
+// One header: packet i's, `space` bytes at byte `at` of the buffer.
+__device__ __forceinline__ void hdr_decode_one(const HdrDecodeArgs &a, const HdrImage &img, uint64_t i, uint64_t at, uint64_t space)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= a.n) return;
     // offsets and lengths may come off the wire (a Message's size vector): a header that does
     // not lie inside the buffer fails without being read
-    const uint64_t at = a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride;
-    uint64_t space = a.hdr_lens ? a.hdr_lens[i] : a.hdr_stride;
     const bool inside = at <= a.hdrs_bytes && space <= a.hdrs_bytes - at;
     const uint8_t *p = a.hdrs + (inside ? at : 0);
     if (!inside) space = 0;
@@ -97,4 +77,33 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_hdr_decode(HdrDecodeArgs a, HdrIm
     if (a.byteorders) a.byteorders[i] = bo;
     if (a.ndests) a.ndests[i] = nd;
     if (a.ok) a.ok[i] = good ? 1 : 0;
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_hdr_decode(HdrDecodeArgs a, HdrImage img)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= a.n) return;
+    hdr_decode_one(a, img, i, a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride, a.hdr_lens ? a.hdr_lens[i] : a.hdr_stride);
+}
+
+// One header written: packet i's at p.
+__device__ __forceinline__ void hdr_encode_one(const HdrEncodeArgs &a, const HdrImage &img, uint64_t i, uint8_t *p)
+{
+    st_u<uint32_t>(p + 0, a.stream_ids ? a.stream_ids[i] : a.stream_id);
+    st_u<int32_t>(p + 4, a.tags ? a.tags[i] : a.tag);
+    st_u<uint32_t>(p + 8, a.src_ranks ? a.src_ranks[i] : a.src_rank);
+    st_u<uint32_t>(p + 12, img.fmt_bytes);
+    for (uint32_t b = 0; b < img.fmt_bytes; b++) p[16 + b] = img.fmt[b];
+    uint8_t *q = p + 16 + img.fmt_bytes;
+    st_u<uint64_t>(q, a.ndest);                 // pdr_uint64(dest count), src/Packet.C:579-585
+    q += 8;
+    for (uint64_t d = 0; d < a.ndest; d++, q += 4) st_u<uint32_t>(q, a.dests[d]);
+    q[0] = (uint8_t)MRPDR_LITTLEENDIAN;         // pdrmem_getbo() of this device
+}
+
+__global__ __launch_bounds__(MRPDR_TPB) void k_hdr_encode(HdrEncodeArgs a, HdrImage img)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (i >= a.n) return;
+    hdr_encode_one(a, img, i, a.hdrs + (a.hdr_offsets ? a.hdr_offsets[i] : i * a.hdr_stride));
 }

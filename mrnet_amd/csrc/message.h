@@ -12,6 +12,8 @@
 #pragma once
 
 #include "common.h"
+#include "header.h"
+#include "scan.h"
 
 #define MSG_COUNT_BYTES 5u      // byteorder flag + u32 count
 
@@ -30,27 +32,99 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_msg_preamble(uint8_t *msg, uint64
     }
 }
 
-// sizes[2n] as received -> hdr_lens, buf_lens and (in buf_offsets, as scratch) hdr+buf per packet.
-// The sizes are untrusted: each enters the sum as at most `clamp` = 2^63 / (n + 1), so neither a pair
-// nor the scan over the pairs can wrap; a clamped size makes the payload total larger than any
-// message that exists, which the length check of the caller (and the bounds checks of the header
-// and data decoders, who get the sizes as received) then refuse.
-__global__ __launch_bounds__(MRPDR_TPB) void k_msg_split(const uint8_t *sizes, uint64_t n, uint64_t clamp,
-                                                         uint64_t *hdr_lens, uint64_t *buf_lens, uint64_t *pair)
+// The sizes of a received message are untrusted: each enters the sums as at most `clamp` =
+// 2^63 / (n + 1), so neither a pair nor the scan over the pairs can wrap; a clamped size makes the
+// payload total larger than any message that exists, which the length check of the caller (and the
+// bounds checks of the header and data decoders, who get the sizes as received) then refuse.
+
+// ---------------------------------------------------------------------------
+// The receive side in two launches (Message::recv, src/Message.C:48-199, which ends by building a
+// Packet from every header buffer: Packet::decode_pdr_header, src/Packet.C:87-104)
+// ---------------------------------------------------------------------------
+#define MSG_BLOCK_PKTS 1024             // packets per workgroup, four per lane
+static_assert(MSG_BLOCK_PKTS == 4 * MRPDR_TPB, "a lane owns four consecutive packets");
+
+// The (clamped) header + data bytes of the lane's four packets.
+__device__ __forceinline__ void msg_load_sizes(const uint8_t *sizes, uint64_t n, uint64_t clamp, uint64_t first,
+                                               uint64_t (&h)[4], uint64_t (&b)[4], uint64_t (&pair)[4])
 {
-    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t h = ld_u<uint64_t>(sizes + 16 * i), b = ld_u<uint64_t>(sizes + 16 * i + 8);
-    hdr_lens[i] = h;
-    buf_lens[i] = b;
-    pair[i] = (h < clamp ? h : clamp) + (b < clamp ? b : clamp);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = first + k < n ? first + k : n - 1;         // unconditional loads, issued together
+        h[k] = ld_u<uint64_t>(sizes + 16 * i);
+        b[k] = ld_u<uint64_t>(sizes + 16 * i + 8);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        pair[k] = first + k < n ? (h[k] < clamp ? h[k] : clamp) + (b[k] < clamp ? b[k] : clamp) : 0;
 }
 
-// hdr_offsets[n+1] = scan of the pairs; the data of packet i follows its header
-__global__ __launch_bounds__(MRPDR_TPB) void k_msg_place(const uint64_t *hdr_offsets, const uint64_t *hdr_lens,
-                                                         uint64_t n, uint64_t *buf_offsets)
+__global__ __launch_bounds__(MRPDR_TPB) void k_msg_sums(const uint8_t *sizes, uint64_t n, uint64_t clamp, uint64_t *block_sums)
+{
+    uint64_t h[4], b[4], pair[4];
+    msg_load_sizes(sizes, n, clamp, (uint64_t)blockIdx.x * MSG_BLOCK_PKTS + threadIdx.x * 4u, h, b, pair);
+    uint64_t total;
+    block_exclusive_scan(pair[0] + pair[1] + pair[2] + pair[3], &total);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// Offsets and lengths of every header and data buffer (relative to the payload), then the headers
+// themselves: the lane that placed a header is not the lane that reads it (reads go lane = packet,
+// so that a wavefront's headers are neighbours), the places pass through LDS.
+__global__ __launch_bounds__(MRPDR_TPB) void k_msg_place_headers(const uint8_t *sizes, uint64_t n, uint64_t clamp,
+                                                                 const uint64_t *block_sums,
+                                                                 uint64_t *hdr_offsets, uint64_t *hdr_lens,
+                                                                 uint64_t *buf_offsets, uint64_t *buf_lens,
+                                                                 HdrDecodeArgs a, HdrImage img)
+{
+    __shared__ uint64_t s_at[MSG_BLOCK_PKTS], s_len[MSG_BLOCK_PKTS];
+    const uint64_t base_pkt = (uint64_t)blockIdx.x * MSG_BLOCK_PKTS;
+    const uint64_t first = base_pkt + threadIdx.x * 4u;
+    uint64_t h[4], b[4], pair[4];
+    msg_load_sizes(sizes, n, clamp, first, h, b, pair);
+    uint64_t s = 0;
+    for (uint64_t j = threadIdx.x; j < blockIdx.x; j += MRPDR_TPB) s += block_sums[j];
+    uint64_t before;
+    block_exclusive_scan(s, &before);
+    uint64_t total;
+    uint64_t run = before + block_exclusive_scan(pair[0] + pair[1] + pair[2] + pair[3], &total);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint64_t i = first + k;
+        if (i < n) {
+            hdr_offsets[i] = run;
+            hdr_lens[i] = h[k];
+            buf_offsets[i] = run + h[k];
+            buf_lens[i] = b[k];
+            s_at[threadIdx.x * 4u + k] = run;
+            s_len[threadIdx.x * 4u + k] = h[k];
+        }
+        run += pair[k];
+        if (i + 1 == n) { hdr_offsets[n] = run; buf_offsets[n] = run; }
+    }
+    if (!a.hdrs) return;                  // the sizes alone (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t j = threadIdx.x + (uint32_t)k * MRPDR_TPB;
+        if (base_pkt + j < n) hdr_decode_one(a, img, base_pkt + j, s_at[j], s_len[j]);
+    }
+}
+
+// The send side's framing in one launch: the preamble entry of packet i and its header, which sits
+// hdr_len bytes in front of its data (Message::send, src/Message.C:201-335, over the header buffer
+// Packet::encode_pdr_header made, src/Packet.C:557-593).
+__global__ __launch_bounds__(MRPDR_TPB) void k_msg_frame(uint8_t *msg, uint64_t n, uint64_t hdr_len, const uint64_t *lens,
+                                                         HdrEncodeArgs a, HdrImage img)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (i < n) buf_offsets[i] = hdr_offsets[i] + hdr_lens[i];
-    if (i == n) buf_offsets[n] = hdr_offsets[n];
+    if (i == 0) {
+        msg[0] = (uint8_t)MRPDR_LITTLEENDIAN;
+        st_u<uint32_t>(msg + 1, (uint32_t)n);
+        msg[MSG_COUNT_BYTES + 16 * n] = 0;
+    }
+    if (i >= n) return;
+    st_u<uint64_t>(msg + MSG_COUNT_BYTES + 16 * i, hdr_len);
+    st_u<uint64_t>(msg + MSG_COUNT_BYTES + 16 * i + 8, lens[i]);
+    hdr_encode_one(a, img, i, a.hdrs + a.hdr_offsets[i]);
 }

@@ -447,11 +447,28 @@ static bool rows_path_ok(const mrpdr_fmt *f, const WireDev &w)
 }
 
 // Waves of short packets (a few hundred bytes on average) take the LDS-staged tile kernels.
+// What has to fit the image is the span of 64 consecutive packets in the arena, whatever lies
+// between them (alignment padding; the packet headers when the arena is a Message): the arena's
+// bytes per packet stand for it, with one part in six of slack for tiles above the average.
 #define TILE_AVG_BYTES 320
+#define TILE_AVG_BYTES_WIDE 448
 static bool tile_path_ok(const mrpdr_fmt *f, const WireDev &w, uint64_t n)
 {
     return !f->fixed && f->nstrarr == 0 && f->nvar <= TILE_MAXV && w.offsets && w.lens && n > 0 &&
-           w.bytes / n <= TILE_AVG_BYTES;
+           w.bytes / n <= TILE_AVG_BYTES_WIDE;
+}
+static bool tile_wide(const WireDev &w, uint64_t n) { return w.bytes / n > TILE_AVG_BYTES; }
+
+// Calls launch(V, IMG) with the format's table size and the wave's image size as constants.
+template <typename F>
+static void tile_variant(bool small, bool wide, F &&launch)
+{
+    typedef std::integral_constant<int, TILE_SMALLV> vs;
+    typedef std::integral_constant<int, TILE_MAXV> vm;
+    typedef std::integral_constant<int, TILE_IMG> in;
+    typedef std::integral_constant<int, TILE_IMG_WIDE> iw;
+    if (small) { if (wide) launch(vs(), iw()); else launch(vs(), in()); }
+    else       { if (wide) launch(vm(), iw()); else launch(vm(), in()); }
 }
 
 static int32_t perf_begin(mrpdr_ctx *c, hipStream_t st, bool *timed, int kind)
@@ -657,8 +674,9 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
         if (!(phases & 2)) return 1;
         bool timed;
         if (!perf_begin(c, st, &timed, 1)) return 0;
-        if (f->tv.nv <= TILE_SMALLV) k_tile_encode<TILE_SMALLV><<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
-        else                         k_tile_encode<TILE_MAXV><<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+        tile_variant(f->tv.nv <= TILE_SMALLV, tile_wide(wd, n), [&](auto v, auto img) {
+            k_tile_encode<decltype(v)::value, decltype(img)::value><<<blocks_for(n, TILE_PKTS), MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+        });
         LAUNCHED("k_tile_encode");
         return perf_end(c, st, timed, 1);
     }
@@ -737,10 +755,12 @@ static int32_t launch_tile_walk(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev 
 {
     const uint32_t tiles = blocks_for(n, TILE_PKTS);
     const bool small = f->tv.nv <= TILE_SMALLV;
-    if (swap) { if (small) k_tile_walk<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-                else       k_tile_walk<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
-    else      { if (small) k_tile_walk<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-                else       k_tile_walk<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt); }
+    const bool wide = tile_wide(wd, n);
+    tile_variant(small, wide, [&](auto v, auto img) {
+        constexpr int V = decltype(v)::value, IMG = decltype(img)::value;
+        if (swap) k_tile_walk<true, V, IMG><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+        else      k_tile_walk<false, V, IMG><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+    });
     LAUNCHED("k_tile_walk");
     return 1;
 }
@@ -761,10 +781,12 @@ static int32_t launch_tile_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDe
     if (!perf_begin(c, st, &timed, 0)) return 0;
     const bool small = f->tv.nv <= TILE_SMALLV;
     const uint32_t tiles = blocks_for(n, TILE_PKTS);
-    if (swap) { if (small) k_tile_decode<true, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
-                else       k_tile_decode<true, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid); }
-    else      { if (small) k_tile_decode<false, TILE_SMALLV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
-                else       k_tile_decode<false, TILE_MAXV><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid); }
+    const bool wide = tile_wide(wd, n);
+    tile_variant(small, wide, [&](auto v, auto img) {
+        constexpr int V = decltype(v)::value, IMG = decltype(img)::value;
+        if (swap) k_tile_decode<true, V, IMG><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
+        else      k_tile_decode<false, V, IMG><<<tiles, MRPDR_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
+    });
     LAUNCHED("k_tile_decode");
     return perf_end(c, st, timed, 0);
 }
@@ -1061,27 +1083,86 @@ extern "C" int32_t mrpdr_message_write_preamble(mrpdr_ctx *c, uint64_t n, uint64
     return 1;
 }
 
+// Size vector -> places (and, with a.hdrs, the headers): two launches.
+static int32_t message_places(const char *who, mrpdr_ctx *c, const uint8_t *sizes, uint64_t n,
+                              uint64_t *hdr_offsets, uint64_t *hdr_lens, uint64_t *buf_offsets, uint64_t *buf_lens,
+                              const HdrDecodeArgs &a, const HdrImage &img, hipStream_t st)
+{
+    if (n > c->max_packets) return fail("%s: n exceeds the ctx limit", who);
+    if (!hdr_offsets || !buf_offsets || (n && (!sizes || !hdr_lens || !buf_lens))) return fail("%s: NULL argument", who);
+    if (n == 0) {
+        HIP_OK(hipMemsetAsync(hdr_offsets, 0, sizeof(uint64_t), st));
+        HIP_OK(hipMemsetAsync(buf_offsets, 0, sizeof(uint64_t), st));
+        return 1;
+    }
+    const uint64_t clamp = (1ull << 63) / (n + 1);
+    const uint32_t blocks = blocks_for(n, MSG_BLOCK_PKTS);
+    k_msg_sums<<<blocks, MRPDR_TPB, 0, st>>>(sizes, n, clamp, c->tile_cnt);
+    LAUNCHED("k_msg_sums");
+    k_msg_place_headers<<<blocks, MRPDR_TPB, 0, st>>>(sizes, n, clamp, c->tile_cnt, hdr_offsets, hdr_lens, buf_offsets, buf_lens, a, img);
+    LAUNCHED("k_msg_place_headers");
+    return 1;
+}
+
 extern "C" int32_t mrpdr_message_parse_sizes(mrpdr_ctx *c, const uint8_t *sizes, uint64_t n,
                                              uint64_t *hdr_offsets, uint64_t *hdr_lens,
                                              uint64_t *buf_offsets, uint64_t *buf_lens,
                                              uint64_t *payload_bytes_host, void *stream)
 {
     if (!ctx_ready("mrpdr_message_parse_sizes", c)) return 0;
-    if (n > c->max_packets) return fail("mrpdr_message_parse_sizes: n exceeds the ctx limit");
-    if (!hdr_offsets || !buf_offsets || (n && (!sizes || !hdr_lens || !buf_lens)))
-        return fail("mrpdr_message_parse_sizes: NULL argument");
     hipStream_t st = (hipStream_t)stream;
-    if (n) {
-        k_msg_split<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(sizes, n, (1ull << 63) / (n + 1), hdr_lens, buf_lens, buf_offsets);
-        LAUNCHED("k_msg_split");
-    }
-    if (!run_scan(c, buf_offsets, n, 1, 0, hdr_offsets, st)) return 0;
-    k_msg_place<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, st>>>(hdr_offsets, hdr_lens, n, buf_offsets);
-    LAUNCHED("k_msg_place");
+    HdrDecodeArgs none;
+    HdrImage img;
+    memset(&none, 0, sizeof none);
+    memset(&img, 0, sizeof img);
+    if (!message_places("mrpdr_message_parse_sizes", c, sizes, n, hdr_offsets, hdr_lens, buf_offsets, buf_lens, none, img, st)) return 0;
     if (payload_bytes_host) {
         HIP_OK(hipMemcpyAsync(payload_bytes_host, hdr_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
     }
+    return 1;
+}
+
+extern "C" int32_t mrpdr_message_parse(mrpdr_ctx *c, const mrpdr_fmt *f, const uint8_t *msg, uint64_t msg_bytes, uint64_t n,
+                                       uint64_t *hdr_offsets, uint64_t *hdr_lens,
+                                       uint64_t *buf_offsets, uint64_t *buf_lens,
+                                       uint32_t *stream_ids, int32_t *tags, uint32_t *src_ranks,
+                                       uint8_t *byteorders, uint64_t *ndests,
+                                       uint32_t *dest_ranks, uint64_t dest_stride, int32_t *hdr_ok, void *stream)
+{
+    const char *who = "mrpdr_message_parse";
+    if (!ctx_ready(who, c)) return 0;
+    HdrImage img;
+    if (!make_image(who, f, &img)) return 0;
+    if (!msg) return fail("%s: NULL message", who);
+    if (n > 0xFFFFFFFFull) return fail("%s: the packet count is a uint32 on the wire", who);
+    const uint64_t pre = mrpdr_message_preamble_bytes(n);
+    if (pre > msg_bytes) return fail("%s: message shorter than its size vector", who);
+    HdrDecodeArgs a = { msg + pre, msg_bytes - pre, nullptr, nullptr, 0, stream_ids, tags, src_ranks,
+                        byteorders, ndests, dest_ranks, dest_stride, hdr_ok, n };
+    return message_places(who, c, msg + MSG_COUNT_BYTES, n, hdr_offsets, hdr_lens, buf_offsets, buf_lens, a, img,
+                          (hipStream_t)stream);
+}
+
+extern "C" int32_t mrpdr_message_write_frame(mrpdr_ctx *c, const mrpdr_fmt *f, uint64_t n,
+                                             const uint64_t *lens, const uint64_t *offsets,
+                                             uint32_t stream_id, const uint32_t *stream_ids,
+                                             int32_t tag, const int32_t *tags,
+                                             uint32_t src_rank, const uint32_t *src_ranks,
+                                             uint8_t *msg, void *stream)
+{
+    const char *who = "mrpdr_message_write_frame";
+    if (!ctx_ready(who, c)) return 0;
+    HdrImage img;
+    if (!make_image(who, f, &img)) return 0;
+    if (!msg || (n && (!lens || !offsets))) return fail("%s: NULL argument", who);
+    if (n > 0xFFFFFFFFull) return fail("%s: the packet count is a uint32 on the wire", who);
+    const uint64_t h = mrpdr_header_bytes(f);
+    // header i sits h bytes in front of packet i's data: offsets[] come from mrpdr_wave_sizeof with phase = h
+    HdrEncodeArgs a = { stream_id, stream_ids, tag, tags, src_rank, src_ranks, nullptr, 0,
+                        msg + mrpdr_message_preamble_bytes(n) - h, offsets, 0, n };
+    k_msg_frame<<<blocks_for(n + 1, MRPDR_TPB), MRPDR_TPB, 0, (hipStream_t)stream>>>(msg, n, h, lens, a, img);
+    LAUNCHED("k_msg_frame");
     return 1;
 }
 

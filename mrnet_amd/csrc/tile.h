@@ -36,9 +36,11 @@
 
 #define TILE_PKTS 64                   // measured: 32-packet tiles are 25-45 % slower
 #define TILE_MAXV 8
-#define TILE_IMG (24 * 1024)
+#define TILE_IMG (24 * 1024)           // the LDS image of a tile: five workgroups per CU
+#define TILE_IMG_WIDE (32 * 1024)      // for waves whose 64-packet spans are longer (four per CU)
 #define TILE_OFFS_PKTS 1024            // packets per workgroup of k_tile_offs
-static_assert(TILE_IMG % (MRPDR_TPB * 16) == 0, "the image is a whole number of workgroup-wide rows of 16-byte pieces");
+static_assert(TILE_IMG % (MRPDR_TPB * 16) == 0 && TILE_IMG_WIDE % (MRPDR_TPB * 16) == 0,
+              "the image is a whole number of workgroup-wide rows of 16-byte pieces");
 static_assert(TILE_PKTS == 64, "the tile kernels give every packet of a tile one lane of a wavefront");
 
 struct TileVars {                       // the variable fields of the format, in order
@@ -85,7 +87,7 @@ __device__ __forceinline__ void st16_u(uint8_t *p, u32x4 v)
 // in one round of global loads; decides whether the tile can be staged.
 // With CAPS the capacities of the values columns are checked against the wave's totals in the
 // same round (offs[n] of every variable field).
-template <bool SEGS, bool CAPS, typename L>
+template <bool SEGS, bool CAPS, int IMG, typename L>
 __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const WireDev &wire,
                                                const ColsDev &cols, uint64_t p0, uint32_t np, uint64_t n)
 {
@@ -118,7 +120,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         const uint64_t s = m.start[t], e = m.end[t];
         bool fine = e >= s && s <= wire.bytes && e - s <= wire.bytes - s;      // inside the arena
         if (t + 1 < np && m.start[t + 1] < e) fine = false;                    // in order, no overlap
-        if (t == 0 && (m.end[np - 1] < s || m.end[np - 1] - s + 32 > TILE_IMG)) fine = false;   // fits the image
+        if (t == 0 && (m.end[np - 1] < s || m.end[np - 1] - s + 32 > IMG)) fine = false;   // fits the image
         if (!fine) m.staged = 0;
         if (t + 1 < np && m.start[t + 1] != e) m.packed = 0;
         if (SEGS && CAPS) {
@@ -150,14 +152,15 @@ __device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &
 
 // Copy of the tile's wire range into the image: aligned 128-bit pieces (the few bytes in front
 // of the first packet and behind the last one that share their 16-byte granule come along).
-// A lane has at most TILE_IMG / (MRPDR_TPB * 16) = 6 pieces; their loads are all issued before
+// A lane has at most IMG / (MRPDR_TPB * 16) = 6 (or 8) pieces; their loads are all issued before
 // the first LDS store, so the lane waits for memory once, not once per piece.  (As compiled
 // before, load - wait - store per piece, a 19 KiB tile cost five round trips in a row.)
+template <int IMG>
 __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase, uint64_t lo, uint64_t hi, uint32_t mis)
 {
-    constexpr int PIECES = TILE_IMG / (MRPDR_TPB * 16);
+    constexpr int PIECES = IMG / (MRPDR_TPB * 16);
     const uint8_t *g = gbase + lo - mis;
-    const uint32_t bytes = (uint32_t)(hi - lo) + mis;          // at most TILE_IMG - 16 (see tile_load_meta)
+    const uint32_t bytes = (uint32_t)(hi - lo) + mis;          // at most IMG - 16 (see tile_load_meta)
     if (bytes == 0) return;
     // loads are unconditional (a lane past the end re-reads the last piece): predicated loads
     // compile to a branch and a wait each, which is the chain this is here to avoid
@@ -508,14 +511,14 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
             *reinterpret_cast<u32x4 *>(out + x) = *reinterpret_cast<const u32x4 *>(src + x);
 }
 
-template <int V>
+template <int V, int IMG>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols, uint64_t n)
 {
     __shared__ TileLdsT<V> m;
-    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
-    tile_load_meta<true, false>(m, tv, wire, cols, p0, np, n);
+    tile_load_meta<true, false, IMG>(m, tv, wire, cols, p0, np, n);
     if (m.staged) tile_encode_body<true>(m, img, fmt, tv, wire, cols, p0, np);
     else          tile_encode_body<false>(m, img, fmt, tv, wire, cols, p0, np);
 }
@@ -523,22 +526,22 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars 
 // ---------------------------------------------------------------------------
 // decode, begin: walk
 // ---------------------------------------------------------------------------
-template <bool SWAP, int V>
+template <bool SWAP, int V, int IMG>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                          uint64_t n, int32_t *ok, uint64_t *tile_sums,
                                                          uint64_t ntiles)
 {
     __shared__ TileLdsT<V> m;
-    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
-    tile_load_meta<false, false>(m, tv, wire, cols, p0, np, n);
+    tile_load_meta<false, false, IMG>(m, tv, wire, cols, p0, np, n);
     const bool staged = m.staged != 0;
     const uint64_t lo = m.start[0];
     const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
     if (staged) {
-        tile_stage_in(img, wire.base, lo, m.end[np - 1], mis);
+        tile_stage_in<IMG>(img, wire.base, lo, m.end[np - 1], mis);
         __syncthreads();
     }
     if (t >= 64) return;                        // one wavefront walks: a lane per packet
@@ -685,12 +688,12 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev co
 // nvalid (optional): the one-call decode -- the scalar columns are written here too, from the
 // image, with k_count_walk's verdict on every packet (field f of packet i is good iff f < nvalid[i];
 // the fields behind a failure read as zero).
-template <bool SWAP, int V>
+template <bool SWAP, int V, int IMG>
 __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                            uint64_t n, uint32_t *status, const uint8_t *nvalid)
 {
     __shared__ TileLdsT<V> m;
-    __shared__ __attribute__((aligned(16))) uint8_t img[TILE_IMG];
+    __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
@@ -699,14 +702,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     const uint32_t good_fields = (nvalid && (t & 63u) < np) ? nvalid[p0 + (t & 63u)] : 0u;
     // a column too small for the wave, or offs[] that do not describe these packets: nothing is
     // written, the status word says so
-    tile_load_meta<true, true>(m, tv, wire, cols, p0, np, n);
+    tile_load_meta<true, true, IMG>(m, tv, wire, cols, p0, np, n);
     const bool skip = m.too_small != 0;          // no payload moves (the scalar columns are still written)
     if (skip && t == 0) atomicOr(status, 1u);
     if (skip && !nvalid) return;
     const bool staged = m.staged != 0;
     if (staged) {
         const uint64_t lo = m.start[0];
-        tile_stage_in(img, wire.base, lo, m.end[np - 1], (uint32_t)((uintptr_t)(wire.base + lo) & 15u));
+        tile_stage_in<IMG>(img, wire.base, lo, m.end[np - 1], (uint32_t)((uintptr_t)(wire.base + lo) & 15u));
     }
     // where every variable field starts in its packet, from the counts (a packet that failed
     // has zero counts from the failed field on, so nothing of it is moved)

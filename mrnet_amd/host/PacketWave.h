@@ -390,19 +390,17 @@ class PacketWave {
         uint64_t payload = 0;
         if (!mrpdr_wave_sizeof(wc_.ctx, fmt_, cols_.data(), n_, 1, (uint32_t)h, d_lens.ptr<uint64_t>(),
                                d_offs.ptr<uint64_t>(), &payload, wc_.stream)) throw PdrError("mrpdr_wave_sizeof");
-        d_out.resize(pre + payload);
-        hip_check(hipMemsetAsync(d_out.ptr<void>(), 0, pre + payload, wc_.stream), "hipMemsetAsync");
+        d_out.resize(pre + payload);                             // every byte of it is written below
         uint8_t *m = d_out.ptr<uint8_t>();
-        if (!mrpdr_message_write_preamble(wc_.ctx, n_, h, d_lens.ptr<uint64_t>(), m, wc_.stream))
-            throw PdrError("mrpdr_message_write_preamble");
+        const uint32_t *src = nullptr;
+        if (src_ranks && n_) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
+        // preamble and headers in one launch, then the data between the headers
+        if (!mrpdr_message_write_frame(wc_.ctx, fmt_, n_, d_lens.ptr<uint64_t>(), d_offs.ptr<uint64_t>(), stream_id_, nullptr,
+                                       tag_, nullptr, 0xFFFFFFFFu, src, m, wc_.stream))
+            throw PdrError("mrpdr_message_write_frame");
         if (n_) {
             mrpdr_wire w{ m + pre, d_offs.ptr<uint64_t>(), d_lens.ptr<uint64_t>(), 0, payload };
             if (!mrpdr_wave_encode(wc_.ctx, fmt_, cols_.data(), n_, &w, wc_.stream)) throw PdrError("mrpdr_wave_encode");
-            const uint32_t *src = nullptr;
-            if (src_ranks) { d_src.upload(src_ranks->data(), 4 * n_, wc_.stream); src = d_src.ptr<uint32_t>(); }
-            if (!mrpdr_wave_encode_headers(wc_.ctx, fmt_, n_, stream_id_, nullptr, tag_, nullptr, 0xFFFFFFFFu, src,
-                                           nullptr, 0, m + pre - h, d_offs.ptr<uint64_t>(), 0, wc_.stream))
-                throw PdrError("mrpdr_wave_encode_headers");
         }
         out.resize(pre + payload);
         d_out.download(out.data(), pre + payload, wc_.stream);

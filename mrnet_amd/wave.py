@@ -493,27 +493,46 @@ class Codec:
     def message_build(self, fmt, cols, n, stream_id=USER_STRM_BASE_ID, tag=FIRST_APPLICATION_TAG,
                       src_rank=UNKNOWN_RANK, src_ranks=None):
         """One Message holding the wave, encoded in place: returns the uint8 device tensor that a
-        single writev would put on the link."""
+        single writev would put on the link.  (One host read: the payload size, to allocate it.)"""
         h = fmt.header_bytes
         lens, offsets, payload = self.sizeof(fmt, cols, n, 1, h)
         pre = int(self._lib.mrpdr_message_preamble_bytes(n))
-        msg = torch.zeros(pre + payload, dtype=torch.uint8, device=self.device)
-        _check(self._lib.mrpdr_message_write_preamble(self.handle, n, h, _ptr(lens), _ptr(msg), _stream()),
-               "mrpdr_message_write_preamble")
-        wire = WireWave(msg[pre:], n, offsets, lens, 0)
-        self.encode_into(fmt, cols, wire)
-        self.encode_headers(fmt, n, stream_id=stream_id, tag=tag, src_rank=src_rank, src_ranks=src_ranks,
-                            out=msg, out_ptr=msg.data_ptr() + pre - h, offsets=offsets)
+        msg = self.empty(pre + payload, torch.uint8)          # every byte of it is written below
+        self.message_build_into(fmt, cols, n, lens, offsets, msg, stream_id, tag, src_rank, src_ranks)
         return msg
 
-    def message_parse(self, fmt, msg, n=None, check_length=True):
+    def message_build_into(self, fmt, cols, n, lens, offsets, msg, stream_id=USER_STRM_BASE_ID,
+                           tag=FIRST_APPLICATION_TAG, src_rank=UNKNOWN_RANK, src_ranks=None):
+        """Frame (preamble + headers, one launch) and data of the wave into msg; lens / offsets from
+        sizeof(fmt, cols, n, 1, fmt.header_bytes).  No host synchronisation."""
+        pre = int(self._lib.mrpdr_message_preamble_bytes(n))
+        _check(self._lib.mrpdr_message_write_frame(self.handle, fmt.handle, n, _ptr(lens), _ptr(offsets),
+                                                   stream_id, None, tag, None, src_rank, _ptr(src_ranks),
+                                                   _ptr(msg), _stream()), "mrpdr_message_write_frame")
+        self.encode_into(fmt, cols, WireWave(msg[pre:], n, offsets, lens, 0))
+
+    def message_workspace(self, n, max_dest=0):
+        """The outputs of message_parse for waves of up to n packets, allocated once."""
+        ws = {
+            "hdr_offs": self.empty(n + 1, torch.int64), "hdr_lens": self.empty(n, torch.int64),
+            "buf_offs": self.empty(n + 1, torch.int64), "buf_lens": self.empty(n, torch.int64),
+            "stream_id": self.empty(n, torch.int32), "tag": self.empty(n, torch.int32),
+            "src_rank": self.empty(n, torch.int32), "byteorder": self.empty(n, torch.uint8),
+            "ndest": self.empty(n, torch.int64), "ok": self.empty(n, torch.int32),
+        }
+        if max_dest:
+            ws["dest_ranks"] = self.empty(n * max_dest, torch.int32).view(n, max_dest)
+        return ws
+
+    def message_parse(self, fmt, msg, n=None, check_length=True, workspace=None, max_dest=0):
         """Message -> (n, header fields, WireWave of the data buffers).  Message::recv reads the
         5-byte count from the socket before it knows how much more to receive (src/Message.C:71-86),
         so a caller that received the message itself passes that count as `n`; without it the
         count is read back from the device buffer here (one synchronisation).  check_length=False
         skips the host-side comparison of the size vector's total with the buffer length (another
         synchronisation): headers and data buffers that do not lie inside the buffer then simply
-        fail as packets (ok = 0), nothing outside the buffer is touched."""
+        fail as packets (ok = 0), nothing outside the buffer is touched.  workspace: the outputs
+        (message_workspace), for a caller that parses message after message."""
         if n is None:
             head = msg[:5].cpu().numpy()
             bo = int(head[0])
@@ -521,21 +540,26 @@ class Codec:
         pre = int(self._lib.mrpdr_message_preamble_bytes(n))
         if pre > msg.numel():
             raise PdrError("message shorter than its size vector")
-        hdr_offs, buf_offs = self.empty(n + 1, torch.int64), self.empty(n + 1, torch.int64)
-        hdr_lens, buf_lens = self.empty(n, torch.int64), self.empty(n, torch.int64)
-        total = C.c_uint64(0)
-        r = self._lib.mrpdr_message_parse_sizes(self.handle, msg.data_ptr() + 5, n, _ptr(hdr_offs),
-                                                _ptr(hdr_lens), _ptr(buf_offs), _ptr(buf_lens),
-                                                C.byref(total) if check_length else None, _stream())
-        _check(r, "mrpdr_message_parse_sizes")
+        ws = self.message_workspace(n, max_dest) if workspace is None else workspace
+        dests = ws.get("dest_ranks")
+        r = self._lib.mrpdr_message_parse(self.handle, fmt.handle, _ptr(msg), msg.numel(), n,
+                                          _ptr(ws["hdr_offs"]), _ptr(ws["hdr_lens"]), _ptr(ws["buf_offs"]),
+                                          _ptr(ws["buf_lens"]), _ptr(ws["stream_id"]), _ptr(ws["tag"]),
+                                          _ptr(ws["src_rank"]), _ptr(ws["byteorder"]), _ptr(ws["ndest"]),
+                                          _ptr(dests), 0 if dests is None else dests.shape[1], _ptr(ws["ok"]),
+                                          _stream())
+        _check(r, "mrpdr_message_parse")
         if check_length:
-            if pre + total.value > msg.numel():
+            total = int(ws["hdr_offs"][n].item()) & (2**64 - 1)          # (a uint64 kept in an int64 tensor)
+            if pre + total > msg.numel():
                 raise PdrError("message shorter than its size vector announces")
-            payload = msg[pre:pre + total.value]
+            payload = msg[pre:pre + total]
         else:
             payload = msg[pre:]
-        hdr = self.decode_headers(fmt, n, payload, offsets=hdr_offs, lens=hdr_lens)
-        return n, hdr, WireWave(payload, n, buf_offs, buf_lens, 0)
+        hdr = {k: ws[k][:n] for k in ("stream_id", "tag", "src_rank", "byteorder", "ndest", "ok")}
+        if dests is not None:
+            hdr["dest_ranks"] = dests[:n]
+        return n, hdr, WireWave(payload, n, ws["buf_offs"], ws["buf_lens"], 0)
 
     # ---- filters -----------------------------------------------------------------------
     def filter_raw(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,

@@ -133,3 +133,45 @@ def test_packet_wave_through_a_message(codec):
     out = wave.to_message()
     torch.cuda.synchronize()
     assert np.array_equal(W.Codec.to_numpy(out), ref)
+
+
+@pytest.mark.parametrize("n", [1, 1023, 1025, 70001])
+def test_one_call_framing_equals_the_separate_calls(codec, n):
+    """mrpdr_message_write_frame / mrpdr_message_parse against write_preamble + encode_headers and
+    parse_sizes + decode_headers: the same bytes, offsets, lengths and header fields, with waves
+    that span many of their 1,024-packet workgroups and sizes that differ from packet to packet."""
+    import ctypes as C
+    from mrnet_amd.wave import _ptr, _stream
+    fmt = W.Format("%d %s")
+    ocols = make_wave("%d %s", n, seed=n, max_count=23)
+    cols = dev_cols(codec, fmt, ocols)
+    ranks = codec.to_device((np.arange(n, dtype=np.uint32) * 5 + 1).astype(np.uint32))
+    msg = codec.message_build(fmt, cols, n, stream_id=(1 << 30) + 9, tag=77, src_ranks=ranks)
+    # the separate calls, into a zeroed buffer of the same size
+    h = fmt.header_bytes
+    lens, offsets, payload = codec.sizeof(fmt, cols, n, 1, h)
+    pre = 6 + 16 * n
+    assert msg.numel() == pre + payload
+    sep = torch.zeros_like(msg)
+    lib = codec._lib
+    assert lib.mrpdr_message_write_preamble(codec.handle, n, h, _ptr(lens), _ptr(sep), _stream())
+    codec.encode_into(fmt, cols, W.WireWave(sep[pre:], n, offsets, lens, 0))
+    codec.encode_headers(fmt, n, stream_id=(1 << 30) + 9, tag=77, src_ranks=ranks, out=sep,
+                         out_ptr=sep.data_ptr() + pre - h, offsets=offsets)
+    assert torch.equal(msg, sep)
+    # and back
+    cnt, hdr, wire = codec.message_parse(fmt, msg, n=n, check_length=False)
+    ho, bo = codec.empty(n + 1, torch.int64), codec.empty(n + 1, torch.int64)
+    hl, bl = codec.empty(n, torch.int64), codec.empty(n, torch.int64)
+    total = C.c_uint64(0)
+    assert lib.mrpdr_message_parse_sizes(codec.handle, msg.data_ptr() + 5, n, _ptr(ho), _ptr(hl), _ptr(bo), _ptr(bl),
+                                         C.byref(total), _stream())
+    assert total.value == payload
+    assert torch.equal(wire.offsets[:n + 1], bo) and torch.equal(wire.lens[:n], bl)
+    assert torch.equal(bo[:n], offsets[:n]) and torch.equal(bl, lens) and int(ho[n]) == payload
+    sep_hdr = codec.decode_headers(fmt, n, msg[pre:], offsets=ho, lens=hl)
+    for k in ("stream_id", "tag", "src_rank", "byteorder", "ndest", "ok"):
+        assert torch.equal(hdr[k], sep_hdr[k]), k
+    assert int(hdr["ok"].sum()) == n and torch.equal(hdr["src_rank"].view(torch.int32), ranks.view(torch.int32))
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert int(ok.sum()) == n and columns_equal(host_cols(fmt, dcols, n), ocols)
