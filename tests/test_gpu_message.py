@@ -175,3 +175,38 @@ def test_one_call_framing_equals_the_separate_calls(codec, n):
     assert int(hdr["ok"].sum()) == n and torch.equal(hdr["src_rank"].view(torch.int32), ranks.view(torch.int32))
     dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
     assert int(ok.sum()) == n and columns_equal(host_cols(fmt, dcols, n), ocols)
+
+
+@pytest.mark.parametrize("n", [700, 4097])
+@pytest.mark.parametrize("giant", [False, True])
+def test_message_of_short_mixed_packets(codec, n, giant):
+    """The mixed short-packet format inside a message: with the 49-byte headers between the data
+    buffers the arena holds 320-448 bytes per packet, the range of the tile kernels' wider LDS
+    image.  With `giant`, one packet is far longer than the image: its tile (and only its tile)
+    runs on global memory.  Build, parse and decode against the oracle, byte for byte."""
+    fmt_s = "%d %uld %lf %s %auc"
+    rng = np.random.default_rng(n + giant)
+    counts = {3: rng.integers(0, 24, n).astype(np.uint64), 4: rng.integers(200, 420, n).astype(np.uint64)}
+    if giant:
+        counts[4][n // 2] = 70000
+    ocols = make_wave(fmt_s, n, seed=n, counts=counts)
+    ranks = np.arange(n, dtype=np.uint32)
+    ref, arena, offs, lens = oracle_message(fmt_s, ocols, n, 1 << 30, 5, ranks)
+    per_packet = (ref.size - (6 + 16 * n)) / n
+    assert 320 < per_packet <= 448 or giant
+    fmt = W.Format(fmt_s)
+    cols = dev_cols(codec, fmt, ocols)
+    msg = codec.message_build(fmt, cols, n, stream_id=1 << 30, tag=5, src_ranks=codec.to_device(ranks))
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(msg), ref)
+    ws = codec.message_workspace(n)
+    cnt, hdr, wire = codec.message_parse(fmt, codec.to_device(ref), n=n, check_length=False, workspace=ws)
+    # both decode forms: the walk that stages the tiles (begin + finish) and the one call
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert int(ok.sum()) == n and int(hdr["ok"].sum()) == n
+    assert columns_equal(host_cols(fmt, dcols, n), ocols)
+    caps = [None, None, None, int(ocols[3]["offs"][-1]), int(ocols[4]["offs"][-1])]
+    d2, ok2 = codec.alloc_columns(fmt, n, caps), codec.empty(n, torch.int32)
+    codec.decode_into(fmt, wire, d2, ok2)
+    assert int(ok2.sum()) == n and columns_equal(host_cols(fmt, d2, n), ocols)
+    assert codec.status() == 0
