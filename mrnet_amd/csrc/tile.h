@@ -15,6 +15,10 @@
 //   decode  k_tile_walk     wire -> LDS; scalars, counts, ok, per-tile count sums     (begin)
 //           k_tile_offs     counts + tile sums -> offs[] of every variable field      (begin)
 //           k_tile_decode   wire -> LDS; payloads -> values columns                   (finish)
+//   decode in one call: k_count_walk (length prefixes only, nothing staged) in place of
+//           k_tile_walk; k_tile_decode then writes the scalar columns too
+// The image is 24 KiB (five workgroups per CU) or, for waves whose 64-packet spans are longer,
+// 32 KiB (four): a template parameter of the kernels, chosen by the host per wave.
 //
 // What a tile costs is a chain of dependent memory round trips, not bytes: measured on a wave of
 // 2^20 packets the HBM traffic is the algorithmic traffic and nothing in the memory system is
