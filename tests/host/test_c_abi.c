@@ -1,6 +1,6 @@
 /* The C ABI from plain C (C99, gcc): what a C back-end library in the style of the reference's
- * src/lightweight/ would write.  One wave of "%d %s %ad" packets is encoded, decoded again and
- * summed; output in the reference's test-harness style (tests/test_common.C:41-187). */
+ * src/lightweight/ would write.  One wave of "%d %s %ad" packets is encoded, decoded again,
+ * summed and sent through a Message; output in the reference's test-harness style (tests/test_common.C:41-187). */
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -101,6 +101,44 @@ int main(void)
     hipMemcpy(&sum, res, 4, hipMemcpyDeviceToHost);
     hipMemcpy(&present, rok, 4, hipMemcpyDeviceToHost);
     end_SubTest("mrpdr_wave_filter(MRPDR_SUM)", ok && present == 1 && sum == (int32_t)want);
+
+    /* Message::send / Message::recv for the wave (src/Message.C:201-335, 48-199): frame and data into
+     * one buffer, then size vector, headers and data out of it again, no host read in between */
+    {
+        const uint64_t h = mrpdr_header_bytes(fmt), pre = mrpdr_message_preamble_bytes(N);
+        uint64_t payload = 0;
+        ok = mrpdr_wave_sizeof(ctx, fmt, cols, N, 1, (uint32_t)h, lens, offs, &payload, NULL);
+        uint8_t *msg = to_device(NULL, pre + payload);
+        ok = ok && mrpdr_message_write_frame(ctx, fmt, N, lens, offs, 0x40000010u, NULL, 101, NULL, 7, NULL, msg, NULL);
+        mrpdr_wire mw = { msg + pre, offs, lens, 0, payload };
+        ok = ok && mrpdr_wave_encode(ctx, fmt, cols, N, &mw, NULL);
+        static uint8_t head[5 + 16];
+        hipMemcpy(head, msg, sizeof head, hipMemcpyDeviceToHost);
+        uint64_t h0 = 0, b0 = 0;
+        memcpy(&h0, head + 5, 8); memcpy(&b0, head + 13, 8);
+        ok = ok && head[0] == MRPDR_LITTLEENDIAN && head[1] == (N & 255) && head[2] == (N >> 8) && h0 == h && b0 == 34;
+        uint64_t *ho = to_device(NULL, 8 * (N + 1)), *hl = to_device(NULL, 8 * N);
+        uint64_t *bo = to_device(NULL, 8 * (N + 1)), *bl = to_device(NULL, 8 * N);
+        uint32_t *sid = to_device(NULL, 4 * N), *src = to_device(NULL, 4 * N);
+        int32_t *tag = to_device(NULL, 4 * N), *hok = to_device(NULL, 4 * N);
+        ok = ok && mrpdr_message_parse(ctx, fmt, msg, pre + payload, N, ho, hl, bo, bl, sid, tag, src, NULL, NULL,
+                                       NULL, 0, hok, NULL);
+        mrpdr_wire rw = { msg + pre, bo, bl, 0, payload };
+        ok = ok && mrpdr_wave_decode(ctx, fmt, &rw, N, MRPDR_LITTLEENDIAN, out, okd, NULL);
+        static uint32_t sidh[N], srch[N];
+        static int32_t tagh[N], hokh[N];
+        uint64_t announced = 0;
+        hipMemcpy(sidh, sid, sizeof sidh, hipMemcpyDeviceToHost); hipMemcpy(srch, src, sizeof srch, hipMemcpyDeviceToHost);
+        hipMemcpy(tagh, tag, sizeof tagh, hipMemcpyDeviceToHost); hipMemcpy(hokh, hok, sizeof hokh, hipMemcpyDeviceToHost);
+        hipMemcpy(&announced, ho + N, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(v2, out[0].values, sizeof v2, hipMemcpyDeviceToHost);
+        hipMemcpy(arr2, out[2].values, sizeof arr2, hipMemcpyDeviceToHost);
+        hipMemcpy(okh, okd, sizeof okh, hipMemcpyDeviceToHost);
+        for (int i = 0; i < N; i++)
+            ok = ok && hokh[i] == 1 && okh[i] == 1 && sidh[i] == 0x40000010u && tagh[i] == 101 && srch[i] == 7;
+        end_SubTest("mrpdr_message_write_frame / mrpdr_message_parse", ok && announced == payload &&
+                                                                       !memcmp(v, v2, sizeof v) && !memcmp(arr, arr2, sizeof arr));
+    }
 
     uint32_t status = 1;
     ok = mrpdr_ctx_status(ctx, NULL, &status) && status == 0;
