@@ -388,7 +388,7 @@ def perfdata_extra(codec):
     return {"c5b_perfdata_avg_us_per_wave": round(t * 1e6, 1)}
 
 
-def mixed_wave_extra(codec, n=65536, key="c4", align=16):
+def mixed_wave_extra(codec, n=65536, key="c4", align=16, amax=512):
     """Config 4: 65,536 packets '%d %uld %lf %s %auc' with variable-length fields (string length
     geometric, mean 12, max 255; byte array length uniform in [0, 512]).  With n = 1,048,576 (key
     c4_x16) the same wave sixteen times over: what the format costs per byte once launches no longer
@@ -397,7 +397,7 @@ def mixed_wave_extra(codec, n=65536, key="c4", align=16):
     fmt = W.Format("%d %uld %lf %s %auc")
     rng = np.random.default_rng(4)
     slen = np.minimum(rng.geometric(1.0 / 12.0, n), 255).astype(np.uint64) + 1      # strlen+1
-    alen = rng.integers(0, 513, n).astype(np.uint64)
+    alen = rng.integers(0, amax + 1, n).astype(np.uint64)
     sbody = rng.integers(33, 127, int(slen.sum()), dtype=np.uint8)
     sbody[np.cumsum(slen).astype(np.int64) - 1] = 0
     cols = codec.columns_from_numpy(fmt, [
