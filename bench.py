@@ -633,7 +633,7 @@ def spawn_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else sys.stderr))
-    rc, live = 0, list(procs)
+    rc, live, failed_at = 0, list(procs), None
     while live:
         time.sleep(0.2)
         for p in list(live):
@@ -642,9 +642,13 @@ def spawn_ranks(n):
                 continue
             live.remove(p)
             if code != 0 and rc == 0:
-                rc = code
-                for q in live:                  # a rank that is gone leaves the others in a barrier
-                    q.terminate()
+                rc, failed_at = code, time.monotonic()
+        # a rank that is gone leaves the others in a barrier: they get a little time to fail by
+        # themselves (and say why), then they are ended
+        if failed_at is not None and time.monotonic() - failed_at > 20.0:
+            for q in live:
+                q.terminate()
+            failed_at = time.monotonic() + 1e9
     return rc
 
 
