@@ -1,5 +1,5 @@
 // BUILD-CHECK STAND-IN.  This is NOT MRNet and not part of the product: it declares, with the
-// signatures of include/mrnet/Packet.h:41-74 and include/mrnet/NetworkTopology.h:227-250 of
+// signatures of include/mrnet/Packet.h:41-88 and include/mrnet/NetworkTopology.h:227-250 of
 // MRNet 5.0.1, only the names integration/mrpdr_filters.C uses, so that `make plugin-check` can
 // compile that file where no MRNet tree is installed.  In an MRNet build the real
 // "mrnet/MRNet.h" is found first and this file plays no part.
@@ -16,8 +16,10 @@ typedef uint32_t Rank;
 
 class Packet {
  public:
+    Packet(unsigned int istream_id, int itag, const char *ifmt, ...);
     Packet(unsigned int istream_id, int itag, const void **idata, const char *ifmt);
     ~Packet();
+    void set_DestroyData(bool b);
     int get_Tag(void) const;
     unsigned int get_StreamId(void) const;
     const char *get_FormatString(void) const;

@@ -1,5 +1,5 @@
 // mrpdr_filters.C -- MRNet filter plugin: the built-in transformation filters TFILTER_SUM /
-// MIN / MAX / AVG computed on an MI355X through libmrpdr.
+// MIN / MAX / AVG and TFILTER_ARRAY_CONCAT computed on an MI355X through libmrpdr.
 //
 // Loaded like any user filter (src/Network.C:1887, src/Filter.C:139-207):
 //
@@ -17,6 +17,11 @@
 // first input, holding what one call of the built-in over the same wave computes, bit for bit
 // (mrpdr_wave_filter with MRPDR_SHAPE_FLAT).  Packets from senders of the other byte order are
 // handled per packet, as Packet::decode_pdr_data does (src/Packet.C:118).
+//
+// mrpdr_ArrayConcat is tfilter_ArrayConcat (src/FilterDefinitions.C:649-810): packets of exactly one
+// array token ("%ad", "%Alf", "%as", ...) in, one packet with the arrays of all of them end to end
+// out.  The wave is decoded on the device (length prefixes stripped, elements of foreign senders
+// reversed); the decoded values column IS the concatenation, so the only other work is its way back.
 //
 // Build inside an MRNet tree:
 //     g++ -shared -fPIC integration/mrpdr_filters.C -I<mrnet>/include -I<mrnet>/xplat/include
@@ -186,6 +191,207 @@ void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector
     out.push_back(PacketPtr(new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fields, fmt_text)));
 }
 
+// ---- TFILTER_ARRAY_CONCAT ---------------------------------------------------------------------
+struct ConcatState {
+    mrpdr_ctx  *ctx;
+    mrpdr_fmt  *fmt;
+    char       *fmt_text;
+    hipStream_t stream;
+    // the wave as received: data buffers end to end in a pinned arena, offsets / lengths / byte orders
+    uint8_t    *h_arena, *d_arena, *h_orders, *d_orders;
+    uint64_t   *h_meta, *d_meta;       // offsets[n+1] then lens[n]
+    size_t      cap_bytes, cap_packets;
+    // the decoded column
+    uint8_t    *d_values;
+    uint64_t   *d_counts, *d_offs, *d_sub_counts, *d_sub_offs;
+    int32_t    *d_ok;
+    size_t      cap_values, cap_sub;
+};
+
+void release_concat(ConcatState *st)
+{
+    if (!st) return;
+    if (st->h_arena) (void)hipHostFree(st->h_arena);
+    if (st->h_orders) (void)hipHostFree(st->h_orders);
+    if (st->h_meta) (void)hipHostFree(st->h_meta);
+    void *dev[] = { st->d_arena, st->d_orders, st->d_meta, st->d_values, st->d_counts, st->d_offs,
+                    st->d_sub_counts, st->d_sub_offs, st->d_ok };
+    for (size_t k = 0; k < sizeof dev / sizeof dev[0]; k++)
+        if (dev[k]) (void)hipFree(dev[k]);
+    if (st->stream) (void)hipStreamDestroy(st->stream);
+    if (st->fmt) mrpdr_fmt_free(st->fmt);
+    if (st->ctx) mrpdr_ctx_destroy(st->ctx);
+    free(st->fmt_text);
+    delete st;
+}
+
+ConcatState *concat_state_for(void **slot, const char *fmt_text)
+{
+    ConcatState *st = static_cast<ConcatState *>(*slot);
+    if (st && strcmp(st->fmt_text, fmt_text) == 0) return st;
+    release_concat(st);
+    *slot = NULL;
+    st = new ConcatState();
+    memset(st, 0, sizeof *st);
+    int device = 0;
+    (void)hipGetDevice(&device);
+    st->ctx = mrpdr_ctx_create(device, MAX_WAVE);
+    st->fmt = mrpdr_fmt_compile(fmt_text);
+    st->fmt_text = strdup(fmt_text);
+    if (!st->ctx || !st->fmt || !st->fmt_text ||
+        !hip_ok(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking), "hipStreamCreate")) {
+        fprintf(stderr, "mrpdr filter: %s\n", mrpdr_last_error());
+        release_concat(st);
+        return NULL;
+    }
+    *slot = st;
+    return st;
+}
+
+template <typename T> bool regrow(T **p, size_t bytes, bool pinned)
+{
+    if (*p) { if (pinned) (void)hipHostFree(*p); else (void)hipFree(*p); }
+    *p = NULL;
+    return pinned ? hip_ok(hipHostMalloc((void **)p, bytes, hipHostMallocDefault), "hipHostMalloc")
+                  : hip_ok(hipMalloc((void **)p, bytes), "hipMalloc");
+}
+
+size_t grown(size_t cap, size_t need, size_t first)
+{
+    if (cap == 0) cap = first;
+    while (cap < need) cap *= 2;
+    return cap;
+}
+
+bool concat_grow(ConcatState *st, size_t n, size_t bytes, size_t width, bool strings)
+{
+    if (n > st->cap_packets) {
+        const size_t cap = grown(st->cap_packets, n, 1024);
+        st->cap_packets = 0;
+        if (!regrow(&st->h_orders, cap, true) || !regrow(&st->d_orders, cap, false) ||
+            !regrow(&st->h_meta, 8 * (2 * cap + 1), true) || !regrow(&st->d_meta, 8 * (2 * cap + 1), false) ||
+            !regrow(&st->d_counts, 8 * cap, false) || !regrow(&st->d_offs, 8 * (cap + 1), false) ||
+            !regrow(&st->d_ok, 4 * cap, false))
+            return false;
+        st->cap_packets = cap;
+    }
+    if (bytes > st->cap_bytes) {
+        const size_t cap = grown(st->cap_bytes, bytes, 1 << 16);
+        st->cap_bytes = 0;
+        if (!regrow(&st->h_arena, cap, true) || !regrow(&st->d_arena, cap, false)) return false;
+        st->cap_bytes = cap;
+    }
+    // every element takes at least its width on the wire, every string at least five bytes
+    const size_t values = bytes / width + 1, subs = strings ? bytes / 5 + 1 : 0;
+    if (values > st->cap_values) {
+        const size_t cap = grown(st->cap_values, values, 1 << 14);
+        st->cap_values = 0;
+        if (!regrow(&st->d_values, cap * width, false)) return false;
+        st->cap_values = cap;
+    }
+    if (subs > st->cap_sub) {
+        const size_t cap = grown(st->cap_sub, subs, 1 << 12);
+        st->cap_sub = 0;
+        if (!regrow(&st->d_sub_counts, 8 * cap, false) || !regrow(&st->d_sub_offs, 8 * (cap + 1), false)) return false;
+        st->cap_sub = cap;
+    }
+    return true;
+}
+
+void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, void **state)
+{
+    const char *name = "mrpdr_ArrayConcat";
+    const size_t n = in.size();
+    if (n == 0) return;
+    if (n > MAX_WAVE) { fprintf(stderr, "%s: a wave of %zu packets is beyond this plugin's limit\n", name, n); return; }
+    const char *fmt_text = in[0]->get_FormatString();
+    ConcatState *st = concat_state_for(state, fmt_text);
+    if (!st) return;
+    const int kind = mrpdr_fmt_nfields(st->fmt) == 1 ? mrpdr_fmt_field_kind(st->fmt, 0) : -1;
+    if (kind != MRPDR_ARRAY && kind != MRPDR_STRING_ARRAY) {        // src/FilterDefinitions.C:672-769
+        fprintf(stderr, "ERROR: tfilter_ArrayConcat() - invalid packet type: (%s)\n", fmt_text);
+        return;
+    }
+    const bool strings = kind == MRPDR_STRING_ARRAY;
+    const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, 0);
+    size_t bytes = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (strcmp(in[i]->get_FormatString(), fmt_text) != 0 || !in[i]->get_Buffer()) {
+            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
+            return;
+        }
+        bytes += (size_t)in[i]->get_BufferLen();
+    }
+    if (!concat_grow(st, n, bytes, width, strings)) return;
+    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
+    uint64_t *offsets = st->h_meta, *lens = st->h_meta + n + 1;
+    bool foreign = false, same = true;
+    size_t at = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Packet &p = *in[i];
+        const size_t len = (size_t)p.get_BufferLen();
+        memcpy(st->h_arena + at, p.get_Buffer(), len);
+        offsets[i] = at; lens[i] = len; at += len;
+        const char *hdr = p.get_Header();
+        const unsigned hdr_len = p.get_HeaderLen();
+        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
+        foreign = foreign || st->h_orders[i] != native;
+        same = same && st->h_orders[i] == st->h_orders[0];
+    }
+    offsets[n] = at;
+    uint64_t *d_offsets = st->d_meta, *d_lens = st->d_meta + n + 1;
+    if (!hip_ok(hipMemcpyAsync(st->d_arena, st->h_arena, bytes ? bytes : 1, hipMemcpyHostToDevice, st->stream), "H2D") ||
+        !hip_ok(hipMemcpyAsync(st->d_meta, st->h_meta, 8 * (2 * n + 1), hipMemcpyHostToDevice, st->stream), "H2D"))
+        return;
+    mrpdr_wire wire = { st->d_arena, d_offsets, d_lens, 0, bytes };
+    mrpdr_column col;
+    memset(&col, 0, sizeof col);
+    col.values = st->d_values; col.counts = st->d_counts; col.offs = st->d_offs;
+    col.capacity = strings ? st->cap_values * width : st->cap_values;
+    if (strings) { col.sub_counts = st->d_sub_counts; col.sub_offs = st->d_sub_offs; col.sub_capacity = st->cap_sub; }
+    int32_t called;
+    if (foreign && !same) {
+        if (!hip_ok(hipMemcpyAsync(st->d_orders, st->h_orders, n, hipMemcpyHostToDevice, st->stream), "H2D")) return;
+        called = mrpdr_wave_decode_mixed(st->ctx, st->fmt, &wire, n, st->d_orders, &col, st->d_ok, st->stream);
+    } else {
+        called = mrpdr_wave_decode(st->ctx, st->fmt, &wire, n, st->h_orders[0], &col, st->d_ok, st->stream);
+    }
+    if (!called) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
+    // a packet that does not decode adds nothing, as one whose unpack fails (:771-782): its count is 0
+    uint64_t total = 0;
+    uint32_t status = 0;
+    if (!hip_ok(hipMemcpyAsync(&total, st->d_offs + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+    if (!mrpdr_ctx_status(st->ctx, st->stream, &status)) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
+    if (status) { fprintf(stderr, "%s: device status %u\n", name, status); return; }
+    if (total > 0xFFFFFFFFull) { fprintf(stderr, "%s: %llu elements do not fit the filter's 32-bit length\n", name, (unsigned long long)total); return; }
+    const bool large = fmt_text[1] == 'A';
+    void *result = NULL;
+    if (!strings) {
+        result = malloc(total ? total * width : 1);
+        if (!result) return;
+        if (total && (!hip_ok(hipMemcpyAsync(result, st->d_values, total * width, hipMemcpyDeviceToHost, st->stream), "D2H") ||
+                      !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))) { free(result); return; }
+    } else {
+        // the strings come back as one block and the places of each; the packet wants one malloc per string
+        std::vector<uint64_t> sub_offs(total + 1);
+        if (!hip_ok(hipMemcpyAsync(sub_offs.data(), st->d_sub_offs, 8 * (total + 1), hipMemcpyDeviceToHost, st->stream), "D2H") ||
+            !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize")) return;
+        std::vector<char> text(sub_offs[total] ? sub_offs[total] : 1);
+        if (sub_offs[total] && (!hip_ok(hipMemcpyAsync(text.data(), st->d_values, sub_offs[total], hipMemcpyDeviceToHost, st->stream), "D2H") ||
+                                !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))) return;
+        char **strs = (char **)malloc((total ? total : 1) * sizeof(char *));
+        if (!strs) return;
+        for (uint64_t j = 0; j < total; j++) strs[j] = strdup(text.data() + sub_offs[j]);
+        result = strs;
+    }
+    // Packet(stream, tag, fmt, array, length): an unsigned length for '%a', a uint64_t one for '%A'
+    // (src/Packet.C:1478-1793); the packet frees the array (and its strings) with it
+    PacketPtr p(large ? new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fmt_text, result, (uint64_t)total)
+                      : new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fmt_text, result, (unsigned)total));
+    p->set_DestroyData(true);
+    out.push_back(p);
+}
+
 } // namespace
 
 extern "C" {
@@ -196,6 +402,7 @@ const char *mrpdr_Sum_format_string = "";
 const char *mrpdr_Min_format_string = "";
 const char *mrpdr_Max_format_string = "";
 const char *mrpdr_Avg_format_string = "";
+const char *mrpdr_ArrayConcat_format_string = "";
 
 void mrpdr_Sum(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> & /* out_reverse */,
                void **state, PacketPtr & /* params */, const TopologyLocalInfo &)
@@ -219,6 +426,12 @@ void mrpdr_Avg(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, st
                PacketPtr &, const TopologyLocalInfo &)
 {
     run(MRPDR_AVG, "mrpdr_Avg", in, out, state);
+}
+
+void mrpdr_ArrayConcat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> &, void **state,
+                       PacketPtr &, const TopologyLocalInfo &)
+{
+    run_concat(in, out, state);
 }
 
 } // extern "C"

@@ -1,11 +1,12 @@
 // Runs integration/mrpdr_filters.C -- the MRNet filter plugin -- without MRNet: the few Packet
 // methods the plugin calls are implemented here over plain host buffers laid out as
 // Packet::pdr_packet_header / pdr_packet_data lay them out (src/Packet.C:557-845), waves are handed
-// to mrpdr_Sum / Min / Max / Avg the way Filter::push_Packets does (src/Filter.C:42-117), and the
-// output packet is compared with the reference fold written out on the host
-// (src/FilterDefinitions.C:100-149, 517-561).  Prints MRNTEST_SUCCESS / MRNTEST_FAILURE lines like
+// to mrpdr_Sum / Min / Max / Avg / ArrayConcat the way Filter::push_Packets does (src/Filter.C:42-117),
+// and the output packet is compared with the reference fold (concatenation) written out on the host
+// (src/FilterDefinitions.C:100-149, 517-561, 649-810).  Prints MRNTEST_SUCCESS / MRNTEST_FAILURE lines like
 // tests/test_common.C:41-187.
 #include <math.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -20,6 +21,8 @@ namespace MRN {
 struct Packet::Impl {
     unsigned stream_id; int tag; std::string fmt;
     std::vector<char> hdr, buf;
+    void *array; uint64_t array_len; bool array_of_strings, destroy;      // what the array constructor was given
+    Impl() : stream_id(0), tag(0), array(NULL), array_len(0), array_of_strings(false), destroy(false) {}
 };
 
 static size_t token_width(const std::string &t)
@@ -54,7 +57,40 @@ Packet::Packet(unsigned int istream_id, int itag, const void **idata, const char
         impl_->buf.insert(impl_->buf.end(), src, src + token_width(t));
     }
 }
-Packet::~Packet() { delete impl_; }
+// Packet(stream, tag, "%a<T>" | "%A<T>" | "%as", array, length): one array field, laid out as
+// pdr_array does (u64 count, then the elements; a string as u32 strlen+1 and its bytes, NUL included)
+Packet::Packet(unsigned int istream_id, int itag, const char *ifmt, ...) : impl_(new Impl())
+{
+    impl_->stream_id = istream_id; impl_->tag = itag; impl_->fmt = ifmt;
+    const std::string t = tokens(ifmt)[0];
+    va_list ap;
+    va_start(ap, ifmt);
+    void *arr = va_arg(ap, void *);
+    const uint64_t len = t[0] == 'A' ? va_arg(ap, uint64_t) : (uint64_t)va_arg(ap, unsigned);
+    va_end(ap);
+    impl_->array = arr; impl_->array_len = len; impl_->array_of_strings = t.substr(1) == "s";
+    impl_->buf.insert(impl_->buf.end(), (const char *)&len, (const char *)&len + 8);
+    if (impl_->array_of_strings) {
+        for (uint64_t j = 0; j < len; j++) {
+            const char *str = ((char **)arr)[j];
+            const uint32_t l = (uint32_t)strlen(str) + 1;
+            impl_->buf.insert(impl_->buf.end(), (const char *)&l, (const char *)&l + 4);
+            impl_->buf.insert(impl_->buf.end(), str, str + l);
+        }
+    } else {
+        impl_->buf.insert(impl_->buf.end(), (const char *)arr, (const char *)arr + len * token_width(t.substr(1)));
+    }
+}
+void Packet::set_DestroyData(bool b) { impl_->destroy = b; }
+Packet::~Packet()
+{
+    if (impl_->destroy && impl_->array) {
+        if (impl_->array_of_strings)
+            for (uint64_t j = 0; j < impl_->array_len; j++) free(((char **)impl_->array)[j]);
+        free(impl_->array);
+    }
+    delete impl_;
+}
 int Packet::get_Tag(void) const { return impl_->tag; }
 unsigned int Packet::get_StreamId(void) const { return impl_->stream_id; }
 const char *Packet::get_FormatString(void) const { return impl_->fmt.c_str(); }
@@ -142,6 +178,100 @@ template <typename T> static void test_type(const char *fmt, uint64_t n, int ord
     }
 }
 
+// ---- mrpdr_ArrayConcat --------------------------------------------------------------------------
+// An array packet as it looks after Message::recv from a sender of byte order `bo`.
+static PacketPtr received_array(const char *fmt, const void *arr, uint64_t len, size_t w, int bo)
+{
+    PacketPtr p(fmt[1] == 'A' ? new Packet(5u, 9, fmt, arr, (uint64_t)len) : new Packet(5u, 9, fmt, arr, (unsigned)len));
+    std::vector<char> &b = p->impl_->buf;
+    if (bo) {
+        for (size_t k = 0; k < 4; k++) std::swap(b[k], b[7 - k]);
+        if (p->impl_->array_of_strings) {
+            size_t at = 8;
+            for (uint64_t j = 0; j < len; j++) {
+                uint32_t l; memcpy(&l, &b[at], 4);
+                std::swap(b[at], b[at + 3]); std::swap(b[at + 1], b[at + 2]);
+                at += 4 + l;
+            }
+        } else {
+            for (uint64_t j = 0; j < len; j++)
+                for (size_t k = 0; k < w / 2; k++) std::swap(b[8 + j * w + k], b[8 + j * w + w - 1 - k]);
+        }
+    }
+    p->impl_->hdr.assign(16 + strlen(fmt) + 1 + 8 + 1, 0);
+    p->impl_->hdr.back() = (char)bo;
+    return p;
+}
+
+template <typename T> static void test_concat(const char *fmt, uint64_t n, int order_mode)
+{
+    std::vector<PacketPtr> in, out, rev;
+    std::vector<T> all;
+    uint64_t x = 1234567 + n * 7 + (uint64_t)order_mode;
+    for (uint64_t i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint64_t len = (x >> 20) % 5 == 0 ? 0 : (x >> 30) % 41;
+        std::vector<T> mine(len);
+        for (uint64_t j = 0; j < len; j++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; mine[j] = (T)(int64_t)(x >> 11); }
+        all.insert(all.end(), mine.begin(), mine.end());
+        const int bo = order_mode == 2 ? (int)(i % 3 == 1) : order_mode;
+        in.push_back(received_array(fmt, mine.data(), len, sizeof(T), bo));
+    }
+    void *state = NULL;
+    PacketPtr params;
+    MRN::TopologyLocalInfo here, *info = &here;
+    mrpdr_ArrayConcat(in, out, rev, &state, params, *info);
+    const uint64_t total = all.size();
+    bool ok = out.size() == 1 && out[0]->get_StreamId() == 5u && out[0]->get_Tag() == 9 && !strcmp(out[0]->get_FormatString(), fmt) &&
+              out[0]->get_BufferLen() == 8 + total * sizeof(T) && !memcmp(out[0]->get_Buffer(), &total, 8) &&
+              (total == 0 || !memcmp(out[0]->get_Buffer() + 8, all.data(), total * sizeof(T)));
+    // the stream's next wave through the same state
+    std::vector<PacketPtr> out2;
+    mrpdr_ArrayConcat(in, out2, rev, &state, params, *info);
+    ok = ok && out2.size() == 1 && out2[0]->get_BufferLen() == out[0]->get_BufferLen() &&
+         !memcmp(out2[0]->get_Buffer(), out[0]->get_Buffer(), (size_t)out[0]->get_BufferLen());
+    release_concat(static_cast<ConcatState *>(state));
+    end_SubTest(std::string("mrpdr_ArrayConcat(") + fmt + ", " + std::to_string(n) + " packets, orders " +
+                (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
+}
+
+static void test_concat_strings(uint64_t n, int order_mode)
+{
+    std::vector<PacketPtr> in, out, rev;
+    std::vector<std::string> all;
+    uint64_t x = 99 + n;
+    for (uint64_t i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint64_t len = (x >> 20) % 4;
+        std::vector<std::string> mine(len);
+        std::vector<char *> ptrs(len);
+        for (uint64_t j = 0; j < len; j++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            mine[j] = std::string((size_t)((x >> 9) % 9), (char)('a' + (x >> 40) % 26)) + std::to_string(i);
+            ptrs[j] = (char *)mine[j].c_str();
+        }
+        all.insert(all.end(), mine.begin(), mine.end());
+        const int bo = order_mode == 2 ? (int)(i % 3 == 1) : order_mode;
+        in.push_back(received_array("%as", ptrs.data(), len, 1, bo));
+    }
+    void *state = NULL;
+    PacketPtr params;
+    MRN::TopologyLocalInfo here, *info = &here;
+    mrpdr_ArrayConcat(in, out, rev, &state, params, *info);
+    std::vector<char> want;
+    const uint64_t total = all.size();
+    want.insert(want.end(), (const char *)&total, (const char *)&total + 8);
+    for (const std::string &str : all) {
+        const uint32_t l = (uint32_t)str.size() + 1;
+        want.insert(want.end(), (const char *)&l, (const char *)&l + 4);
+        want.insert(want.end(), str.c_str(), str.c_str() + l);
+    }
+    const bool ok = out.size() == 1 && out[0]->get_BufferLen() == want.size() && !memcmp(out[0]->get_Buffer(), want.data(), want.size());
+    release_concat(static_cast<ConcatState *>(state));
+    end_SubTest(std::string("mrpdr_ArrayConcat(%as, ") + std::to_string(n) + " packets, orders " +
+                (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
+}
+
 int main()
 {
     int ndev = 0;
@@ -154,6 +284,27 @@ int main()
             test_type<float>("%f", n, mode);
             test_type<double>("%lf", n, mode);
         }
+    for (uint64_t n : { (uint64_t)1, (uint64_t)5, (uint64_t)1025, (uint64_t)20000 })
+        for (int mode = 0; mode < 3; mode++) {
+            test_concat<int32_t>("%ad", n, mode);
+            test_concat<uint8_t>("%auc", n, mode);
+            test_concat<int16_t>("%ahd", n, mode);
+            test_concat<double>("%alf", n, mode);
+            test_concat<int64_t>("%Ald", n, mode);
+            test_concat_strings(n, mode);
+        }
+    {   // a scalar format is not an array: nothing comes out (src/FilterDefinitions.C:764-768)
+        std::vector<PacketPtr> in, out, rev;
+        int32_t a = 1;
+        const void *f[1] = { &a };
+        in.push_back(received(7, 100, "%d", f, 0));
+        void *state = NULL;
+        PacketPtr params;
+        MRN::TopologyLocalInfo here, *info = &here;
+        mrpdr_ArrayConcat(in, out, rev, &state, params, *info);
+        release_concat(static_cast<ConcatState *>(state));
+        end_SubTest("mrpdr_ArrayConcat refuses a scalar format", out.empty());
+    }
     // a format the built-ins refuse, and a wave whose packets do not share one format: no output
     {
         std::vector<PacketPtr> in, out, rev;
