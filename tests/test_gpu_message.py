@@ -210,3 +210,39 @@ def test_message_of_short_mixed_packets(codec, n, giant):
     codec.decode_into(fmt, wire, d2, ok2)
     assert int(ok2.sum()) == n and columns_equal(host_cols(fmt, d2, n), ocols)
     assert codec.status() == 0
+
+
+def test_downstream_message_with_destination_lists(codec):
+    """A downstream message: every header carries a destination list (src/Packet.C:579-585), so the
+    headers are longer than mrpdr_header_bytes.  Built from the separate calls (sizeof with the longer
+    phase, preamble, headers with dest_ranks, data), checked against the oracle's bytes, and taken
+    apart by the one-call parse with room for the destinations."""
+    fmt_s, n = "%d %auc", 1500
+    ocols = make_wave(fmt_s, n, seed=77, max_count=19)
+    dest = np.array([4, 8, 15, 16], np.uint32)
+    fmt = W.Format(fmt_s)
+    cols = dev_cols(codec, fmt, ocols)
+    h = len(O.header_encode(1 << 30, 3, 0, fmt_s, dest=dest.tolist()))
+    assert h == fmt.header_bytes + 4 * dest.size
+    lens, offsets, payload = codec.sizeof(fmt, cols, n, 1, h)
+    pre = 6 + 16 * n
+    msg = torch.zeros(pre + payload, dtype=torch.uint8, device=codec.device)
+    from mrnet_amd.wave import _ptr, _stream
+    assert codec._lib.mrpdr_message_write_preamble(codec.handle, n, h, _ptr(lens), _ptr(msg), _stream())
+    codec.encode_into(fmt, cols, W.WireWave(msg[pre:], n, offsets, lens, 0))
+    ranks = codec.to_device(np.arange(n, dtype=np.uint32))
+    codec.encode_headers(fmt, n, stream_id=1 << 30, tag=3, src_ranks=ranks, out=msg, out_ptr=msg.data_ptr() + pre - h,
+                         offsets=offsets, dest_ranks=codec.to_device(dest))
+    # the oracle's message of the same packets
+    arena, aoffs, alens = O.wave_encode(fmt_s, ocols, n)
+    hdrs = np.concatenate([O.header_encode(1 << 30, 3, i, fmt_s, dest=dest.tolist()) for i in range(n)])
+    ref = O.message_build(hdrs, np.arange(n, dtype=np.uint64) * np.uint64(h), np.full(n, h, np.uint64), arena, aoffs[:n], alens)
+    torch.cuda.synchronize()
+    assert np.array_equal(W.Codec.to_numpy(msg), ref)
+    ws = codec.message_workspace(n, max_dest=6)
+    cnt, hdr, wire = codec.message_parse(fmt, msg, n=n, workspace=ws)
+    assert int(hdr["ok"].sum()) == n and bool((hdr["ndest"] == dest.size).all())
+    assert np.array_equal(W.Codec.to_numpy(hdr["dest_ranks"]).view(np.uint32)[:, :4], np.tile(dest, (n, 1)))
+    assert torch.equal(hdr["src_rank"].view(torch.int32), ranks.view(torch.int32))
+    dcols, ok = codec.decode(fmt, wire, W.LITTLEENDIAN)
+    assert int(ok.sum()) == n and columns_equal(host_cols(fmt, dcols, n), ocols)
