@@ -1,5 +1,5 @@
 // mrpdr_filters.C -- MRNet filter plugin: the built-in transformation filters TFILTER_SUM /
-// MIN / MAX / AVG and TFILTER_ARRAY_CONCAT computed on an MI355X through libmrpdr.
+// MIN / MAX / AVG, TFILTER_ARRAY_CONCAT and TFILTER_INT_EQ_CLASS computed on an MI355X through libmrpdr.
 //
 // Loaded like any user filter (src/Network.C:1887, src/Filter.C:139-207):
 //
@@ -22,6 +22,8 @@
 // array token ("%ad", "%Alf", "%as", ...) in, one packet with the arrays of all of them end to end
 // out.  The wave is decoded on the device (length prefixes stripped, elements of foreign senders
 // reversed); the decoded values column IS the concatenation, so the only other work is its way back.
+// mrpdr_IntEqClass is tfilter_IntEqClass (:812-902) over "%aud %aud %aud" packets, through
+// mrpdr_wave_int_eq_class.
 //
 // Build inside an MRNet tree:
 //     g++ -shared -fPIC integration/mrpdr_filters.C -I<mrnet>/include -I<mrnet>/xplat/include
@@ -191,8 +193,10 @@ void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector
     out.push_back(PacketPtr(new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fields, fmt_text)));
 }
 
-// ---- TFILTER_ARRAY_CONCAT ---------------------------------------------------------------------
-struct ConcatState {
+// ---- filters over packets of arrays: TFILTER_ARRAY_CONCAT, TFILTER_INT_EQ_CLASS ------------------
+const int MAX_ARRAY_FIELDS = 3;
+
+struct VarState {
     mrpdr_ctx  *ctx;
     mrpdr_fmt  *fmt;
     char       *fmt_text;
@@ -201,21 +205,28 @@ struct ConcatState {
     uint8_t    *h_arena, *d_arena, *h_orders, *d_orders;
     uint64_t   *h_meta, *d_meta;       // offsets[n+1] then lens[n]
     size_t      cap_bytes, cap_packets;
-    // the decoded column
-    uint8_t    *d_values;
-    uint64_t   *d_counts, *d_offs, *d_sub_counts, *d_sub_offs;
+    // the decoded columns, one per field
+    uint8_t    *d_values[MAX_ARRAY_FIELDS];
+    uint64_t   *d_counts[MAX_ARRAY_FIELDS], *d_offs[MAX_ARRAY_FIELDS], *d_sub_counts, *d_sub_offs;
     int32_t    *d_ok;
-    size_t      cap_values, cap_sub;
+    size_t      cap_values[MAX_ARRAY_FIELDS], cap_sub;
+    // TFILTER_INT_EQ_CLASS: the columns of the output packet and the call's scratch
+    uint32_t   *d_out[3];
+    uint64_t   *d_out_meta;            // per output column: counts[1], offs[2]
+    uint8_t    *d_scratch;
+    size_t      cap_out[3], cap_scratch;
 };
 
-void release_concat(ConcatState *st)
+void release_var(VarState *st)
 {
     if (!st) return;
     if (st->h_arena) (void)hipHostFree(st->h_arena);
     if (st->h_orders) (void)hipHostFree(st->h_orders);
     if (st->h_meta) (void)hipHostFree(st->h_meta);
-    void *dev[] = { st->d_arena, st->d_orders, st->d_meta, st->d_values, st->d_counts, st->d_offs,
-                    st->d_sub_counts, st->d_sub_offs, st->d_ok };
+    void *dev[] = { st->d_arena, st->d_orders, st->d_meta, st->d_values[0], st->d_values[1], st->d_values[2],
+                    st->d_counts[0], st->d_counts[1], st->d_counts[2], st->d_offs[0], st->d_offs[1], st->d_offs[2],
+                    st->d_sub_counts, st->d_sub_offs, st->d_ok, st->d_out[0], st->d_out[1], st->d_out[2],
+                    st->d_out_meta, st->d_scratch };
     for (size_t k = 0; k < sizeof dev / sizeof dev[0]; k++)
         if (dev[k]) (void)hipFree(dev[k]);
     if (st->stream) (void)hipStreamDestroy(st->stream);
@@ -225,13 +236,13 @@ void release_concat(ConcatState *st)
     delete st;
 }
 
-ConcatState *concat_state_for(void **slot, const char *fmt_text)
+VarState *var_state_for(void **slot, const char *fmt_text)
 {
-    ConcatState *st = static_cast<ConcatState *>(*slot);
+    VarState *st = static_cast<VarState *>(*slot);
     if (st && strcmp(st->fmt_text, fmt_text) == 0) return st;
-    release_concat(st);
+    release_var(st);
     *slot = NULL;
-    st = new ConcatState();
+    st = new VarState();
     memset(st, 0, sizeof *st);
     int device = 0;
     (void)hipGetDevice(&device);
@@ -241,7 +252,7 @@ ConcatState *concat_state_for(void **slot, const char *fmt_text)
     if (!st->ctx || !st->fmt || !st->fmt_text ||
         !hip_ok(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking), "hipStreamCreate")) {
         fprintf(stderr, "mrpdr filter: %s\n", mrpdr_last_error());
-        release_concat(st);
+        release_var(st);
         return NULL;
     }
     *slot = st;
@@ -263,16 +274,18 @@ size_t grown(size_t cap, size_t need, size_t first)
     return cap;
 }
 
-bool concat_grow(ConcatState *st, size_t n, size_t bytes, size_t width, bool strings)
+// Room for a wave of n packets and `bytes` data bytes whose format has nf array fields.
+bool var_grow(VarState *st, size_t n, size_t bytes, int nf, bool strings)
 {
     if (n > st->cap_packets) {
         const size_t cap = grown(st->cap_packets, n, 1024);
         st->cap_packets = 0;
         if (!regrow(&st->h_orders, cap, true) || !regrow(&st->d_orders, cap, false) ||
             !regrow(&st->h_meta, 8 * (2 * cap + 1), true) || !regrow(&st->d_meta, 8 * (2 * cap + 1), false) ||
-            !regrow(&st->d_counts, 8 * cap, false) || !regrow(&st->d_offs, 8 * (cap + 1), false) ||
             !regrow(&st->d_ok, 4 * cap, false))
             return false;
+        for (int f = 0; f < MAX_ARRAY_FIELDS; f++)
+            if (!regrow(&st->d_counts[f], 8 * cap, false) || !regrow(&st->d_offs[f], 8 * (cap + 1), false)) return false;
         st->cap_packets = cap;
     }
     if (bytes > st->cap_bytes) {
@@ -282,19 +295,86 @@ bool concat_grow(ConcatState *st, size_t n, size_t bytes, size_t width, bool str
         st->cap_bytes = cap;
     }
     // every element takes at least its width on the wire, every string at least five bytes
-    const size_t values = bytes / width + 1, subs = strings ? bytes / 5 + 1 : 0;
-    if (values > st->cap_values) {
-        const size_t cap = grown(st->cap_values, values, 1 << 14);
-        st->cap_values = 0;
-        if (!regrow(&st->d_values, cap * width, false)) return false;
-        st->cap_values = cap;
+    for (int f = 0; f < nf; f++) {
+        const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, f), values = bytes / width + 1;
+        if (values <= st->cap_values[f]) continue;
+        const size_t cap = grown(st->cap_values[f], values, 1 << 14);
+        st->cap_values[f] = 0;
+        if (!regrow(&st->d_values[f], cap * width, false)) return false;
+        st->cap_values[f] = cap;
     }
+    const size_t subs = strings ? bytes / 5 + 1 : 0;
     if (subs > st->cap_sub) {
         const size_t cap = grown(st->cap_sub, subs, 1 << 12);
         st->cap_sub = 0;
         if (!regrow(&st->d_sub_counts, 8 * cap, false) || !regrow(&st->d_sub_offs, 8 * (cap + 1), false)) return false;
         st->cap_sub = cap;
     }
+    return true;
+}
+
+// The wave into the arena and onto the device, decoded into cols[nf] (every packet with its own
+// sender's byte order).  False: nothing to emit (a message has been printed).
+bool gather_and_decode(const char *name, VarState *st, const std::vector<PacketPtr> &in, int nf, bool strings,
+                       mrpdr_column *cols)
+{
+    const size_t n = in.size();
+    const char *fmt_text = st->fmt_text;
+    size_t bytes = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (strcmp(in[i]->get_FormatString(), fmt_text) != 0 || !in[i]->get_Buffer()) {
+            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
+            return false;
+        }
+        bytes += (size_t)in[i]->get_BufferLen();
+    }
+    if (!var_grow(st, n, bytes, nf, strings)) return false;
+    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
+    uint64_t *offsets = st->h_meta, *lens = st->h_meta + n + 1;
+    bool same = true;
+    size_t at = 0;
+    for (size_t i = 0; i < n; i++) {
+        const Packet &p = *in[i];
+        const size_t len = (size_t)p.get_BufferLen();
+        memcpy(st->h_arena + at, p.get_Buffer(), len);
+        offsets[i] = at; lens[i] = len; at += len;
+        // a received packet carries its sender's byte order as the last byte of its header
+        // (src/Packet.C:96); a packet made on this node has native order and possibly no header yet
+        const char *hdr = p.get_Header();
+        const unsigned hdr_len = p.get_HeaderLen();
+        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
+        same = same && st->h_orders[i] == st->h_orders[0];
+    }
+    offsets[n] = at;
+    uint64_t *d_offsets = st->d_meta, *d_lens = st->d_meta + n + 1;
+    if (!hip_ok(hipMemcpyAsync(st->d_arena, st->h_arena, bytes ? bytes : 1, hipMemcpyHostToDevice, st->stream), "H2D") ||
+        !hip_ok(hipMemcpyAsync(st->d_meta, st->h_meta, 8 * (2 * n + 1), hipMemcpyHostToDevice, st->stream), "H2D"))
+        return false;
+    mrpdr_wire wire = { st->d_arena, d_offsets, d_lens, 0, bytes };
+    memset(cols, 0, nf * sizeof *cols);
+    for (int f = 0; f < nf; f++) {
+        const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, f);
+        cols[f].values = st->d_values[f]; cols[f].counts = st->d_counts[f]; cols[f].offs = st->d_offs[f];
+        cols[f].capacity = strings ? st->cap_values[f] * width : st->cap_values[f];
+    }
+    if (strings) { cols[0].sub_counts = st->d_sub_counts; cols[0].sub_offs = st->d_sub_offs; cols[0].sub_capacity = st->cap_sub; }
+    int32_t called;
+    if (!same) {
+        if (!hip_ok(hipMemcpyAsync(st->d_orders, st->h_orders, n, hipMemcpyHostToDevice, st->stream), "H2D")) return false;
+        called = mrpdr_wave_decode_mixed(st->ctx, st->fmt, &wire, n, st->d_orders, cols, st->d_ok, st->stream);
+    } else {
+        called = mrpdr_wave_decode(st->ctx, st->fmt, &wire, n, st->h_orders[0], cols, st->d_ok, st->stream);
+    }
+    if (!called) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return false; }
+    return true;
+}
+
+// Reads and clears the ctx's status word (this also waits for the stream); false when it is set.
+bool device_fine(const char *name, VarState *st)
+{
+    uint32_t status = 0;
+    if (!mrpdr_ctx_status(st->ctx, st->stream, &status)) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return false; }
+    if (status) { fprintf(stderr, "%s: device status %u\n", name, status); return false; }
     return true;
 }
 
@@ -305,7 +385,7 @@ void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, v
     if (n == 0) return;
     if (n > MAX_WAVE) { fprintf(stderr, "%s: a wave of %zu packets is beyond this plugin's limit\n", name, n); return; }
     const char *fmt_text = in[0]->get_FormatString();
-    ConcatState *st = concat_state_for(state, fmt_text);
+    VarState *st = var_state_for(state, fmt_text);
     if (!st) return;
     const int kind = mrpdr_fmt_nfields(st->fmt) == 1 ? mrpdr_fmt_field_kind(st->fmt, 0) : -1;
     if (kind != MRPDR_ARRAY && kind != MRPDR_STRING_ARRAY) {        // src/FilterDefinitions.C:672-769
@@ -314,62 +394,19 @@ void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, v
     }
     const bool strings = kind == MRPDR_STRING_ARRAY;
     const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, 0);
-    size_t bytes = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (strcmp(in[i]->get_FormatString(), fmt_text) != 0 || !in[i]->get_Buffer()) {
-            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
-            return;
-        }
-        bytes += (size_t)in[i]->get_BufferLen();
-    }
-    if (!concat_grow(st, n, bytes, width, strings)) return;
-    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
-    uint64_t *offsets = st->h_meta, *lens = st->h_meta + n + 1;
-    bool foreign = false, same = true;
-    size_t at = 0;
-    for (size_t i = 0; i < n; i++) {
-        const Packet &p = *in[i];
-        const size_t len = (size_t)p.get_BufferLen();
-        memcpy(st->h_arena + at, p.get_Buffer(), len);
-        offsets[i] = at; lens[i] = len; at += len;
-        const char *hdr = p.get_Header();
-        const unsigned hdr_len = p.get_HeaderLen();
-        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
-        foreign = foreign || st->h_orders[i] != native;
-        same = same && st->h_orders[i] == st->h_orders[0];
-    }
-    offsets[n] = at;
-    uint64_t *d_offsets = st->d_meta, *d_lens = st->d_meta + n + 1;
-    if (!hip_ok(hipMemcpyAsync(st->d_arena, st->h_arena, bytes ? bytes : 1, hipMemcpyHostToDevice, st->stream), "H2D") ||
-        !hip_ok(hipMemcpyAsync(st->d_meta, st->h_meta, 8 * (2 * n + 1), hipMemcpyHostToDevice, st->stream), "H2D"))
-        return;
-    mrpdr_wire wire = { st->d_arena, d_offsets, d_lens, 0, bytes };
     mrpdr_column col;
-    memset(&col, 0, sizeof col);
-    col.values = st->d_values; col.counts = st->d_counts; col.offs = st->d_offs;
-    col.capacity = strings ? st->cap_values * width : st->cap_values;
-    if (strings) { col.sub_counts = st->d_sub_counts; col.sub_offs = st->d_sub_offs; col.sub_capacity = st->cap_sub; }
-    int32_t called;
-    if (foreign && !same) {
-        if (!hip_ok(hipMemcpyAsync(st->d_orders, st->h_orders, n, hipMemcpyHostToDevice, st->stream), "H2D")) return;
-        called = mrpdr_wave_decode_mixed(st->ctx, st->fmt, &wire, n, st->d_orders, &col, st->d_ok, st->stream);
-    } else {
-        called = mrpdr_wave_decode(st->ctx, st->fmt, &wire, n, st->h_orders[0], &col, st->d_ok, st->stream);
-    }
-    if (!called) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
+    if (!gather_and_decode(name, st, in, 1, strings, &col)) return;
     // a packet that does not decode adds nothing, as one whose unpack fails (:771-782): its count is 0
     uint64_t total = 0;
-    uint32_t status = 0;
-    if (!hip_ok(hipMemcpyAsync(&total, st->d_offs + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
-    if (!mrpdr_ctx_status(st->ctx, st->stream, &status)) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
-    if (status) { fprintf(stderr, "%s: device status %u\n", name, status); return; }
+    if (!hip_ok(hipMemcpyAsync(&total, st->d_offs[0] + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+    if (!device_fine(name, st)) return;
     if (total > 0xFFFFFFFFull) { fprintf(stderr, "%s: %llu elements do not fit the filter's 32-bit length\n", name, (unsigned long long)total); return; }
     const bool large = fmt_text[1] == 'A';
     void *result = NULL;
     if (!strings) {
         result = malloc(total ? total * width : 1);
         if (!result) return;
-        if (total && (!hip_ok(hipMemcpyAsync(result, st->d_values, total * width, hipMemcpyDeviceToHost, st->stream), "D2H") ||
+        if (total && (!hip_ok(hipMemcpyAsync(result, st->d_values[0], total * width, hipMemcpyDeviceToHost, st->stream), "D2H") ||
                       !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))) { free(result); return; }
     } else {
         // the strings come back as one block and the places of each; the packet wants one malloc per string
@@ -377,7 +414,7 @@ void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, v
         if (!hip_ok(hipMemcpyAsync(sub_offs.data(), st->d_sub_offs, 8 * (total + 1), hipMemcpyDeviceToHost, st->stream), "D2H") ||
             !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize")) return;
         std::vector<char> text(sub_offs[total] ? sub_offs[total] : 1);
-        if (sub_offs[total] && (!hip_ok(hipMemcpyAsync(text.data(), st->d_values, sub_offs[total], hipMemcpyDeviceToHost, st->stream), "D2H") ||
+        if (sub_offs[total] && (!hip_ok(hipMemcpyAsync(text.data(), st->d_values[0], sub_offs[total], hipMemcpyDeviceToHost, st->stream), "D2H") ||
                                 !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))) return;
         char **strs = (char **)malloc((total ? total : 1) * sizeof(char *));
         if (!strs) return;
@@ -392,6 +429,64 @@ void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, v
     out.push_back(p);
 }
 
+// tfilter_IntEqClass (src/FilterDefinitions.C:812-902): "%aud %aud %aud" packets of (class values,
+// members per class, members) in, the classes of all of them merged by value out.
+void run_eq_class(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, void **state)
+{
+    const char *name = "mrpdr_IntEqClass";
+    const size_t n = in.size();
+    if (n == 0) return;
+    if (n > MAX_WAVE) { fprintf(stderr, "%s: a wave of %zu packets is beyond this plugin's limit\n", name, n); return; }
+    const char *fmt_text = in[0]->get_FormatString();
+    VarState *st = var_state_for(state, fmt_text);
+    if (!st) return;
+    bool fits = mrpdr_fmt_nfields(st->fmt) == 3;
+    for (int f = 0; fits && f < 3; f++)
+        fits = mrpdr_fmt_field_kind(st->fmt, f) == MRPDR_ARRAY && mrpdr_fmt_field_width(st->fmt, f) == 4;
+    if (!fits) { fprintf(stderr, "ERROR: %s() - invalid packet type: (%s)\n", name, fmt_text); return; }
+    mrpdr_column cols[3];
+    if (!gather_and_decode(name, st, in, 3, false, cols)) return;
+    // outputs are bounded by the inputs: no more classes than class entries, no more members than came in
+    const size_t want[3] = { st->cap_values[0], st->cap_values[0], st->cap_values[2] };
+    for (int k = 0; k < 3; k++) {
+        if (want[k] <= st->cap_out[k]) continue;
+        st->cap_out[k] = 0;
+        if (!regrow(&st->d_out[k], 4 * want[k], false)) return;
+        st->cap_out[k] = want[k];
+    }
+    if (!st->d_out_meta && !regrow(&st->d_out_meta, 8 * 9, false)) return;
+    const size_t scratch = (size_t)mrpdr_eqclass_scratch_bytes(cols[0].capacity);
+    if (scratch > st->cap_scratch) {
+        st->cap_scratch = 0;
+        if (!regrow(&st->d_scratch, scratch, false)) return;
+        st->cap_scratch = scratch;
+    }
+    mrpdr_column oc[3];
+    memset(oc, 0, sizeof oc);
+    for (int k = 0; k < 3; k++) {
+        oc[k].values = st->d_out[k]; oc[k].counts = st->d_out_meta + 3 * k; oc[k].offs = st->d_out_meta + 3 * k + 1;
+        oc[k].capacity = st->cap_out[k];
+    }
+    if (!mrpdr_wave_int_eq_class(st->ctx, &cols[0], &cols[1], &cols[2], n, &oc[0], &oc[1], &oc[2], st->d_scratch, scratch, st->stream)) {
+        fprintf(stderr, "%s: %s\n", name, mrpdr_last_error());
+        return;
+    }
+    uint64_t meta[9];
+    if (!hip_ok(hipMemcpyAsync(meta, st->d_out_meta, sizeof meta, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+    if (!device_fine(name, st)) return;
+    const uint64_t nclasses = meta[0], nmems = meta[6];
+    std::vector<uint32_t> vals(nclasses ? nclasses : 1), memcnts(nclasses ? nclasses : 1), mems(nmems ? nmems : 1);
+    if ((nclasses && (!hip_ok(hipMemcpyAsync(vals.data(), st->d_out[0], 4 * nclasses, hipMemcpyDeviceToHost, st->stream), "D2H") ||
+                      !hip_ok(hipMemcpyAsync(memcnts.data(), st->d_out[1], 4 * nclasses, hipMemcpyDeviceToHost, st->stream), "D2H"))) ||
+        (nmems && !hip_ok(hipMemcpyAsync(mems.data(), st->d_out[2], 4 * nmems, hipMemcpyDeviceToHost, st->stream), "D2H")) ||
+        !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))
+        return;
+    // (the packet encodes its arguments when it is made, :877-882; the arrays need not outlive this call)
+    out.push_back(PacketPtr(new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), "%aud %aud %aud",
+                                       vals.data(), (unsigned)nclasses, memcnts.data(), (unsigned)nclasses,
+                                       mems.data(), (unsigned)nmems)));
+}
+
 } // namespace
 
 extern "C" {
@@ -403,6 +498,7 @@ const char *mrpdr_Min_format_string = "";
 const char *mrpdr_Max_format_string = "";
 const char *mrpdr_Avg_format_string = "";
 const char *mrpdr_ArrayConcat_format_string = "";
+const char *mrpdr_IntEqClass_format_string = "";
 
 void mrpdr_Sum(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> & /* out_reverse */,
                void **state, PacketPtr & /* params */, const TopologyLocalInfo &)
@@ -432,6 +528,12 @@ void mrpdr_ArrayConcat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> 
                        PacketPtr &, const TopologyLocalInfo &)
 {
     run_concat(in, out, state);
+}
+
+void mrpdr_IntEqClass(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, std::vector<PacketPtr> &, void **state,
+                      PacketPtr &, const TopologyLocalInfo &)
+{
+    run_eq_class(in, out, state);
 }
 
 } // extern "C"

@@ -57,29 +57,31 @@ Packet::Packet(unsigned int istream_id, int itag, const void **idata, const char
         impl_->buf.insert(impl_->buf.end(), src, src + token_width(t));
     }
 }
-// Packet(stream, tag, "%a<T>" | "%A<T>" | "%as", array, length): one array field, laid out as
-// pdr_array does (u64 count, then the elements; a string as u32 strlen+1 and its bytes, NUL included)
+// Packet(stream, tag, "%a<T> ..." | "%A<T>" | "%as", array, length, ...): array fields, each laid out
+// as pdr_array does (u64 count, then the elements; a string as u32 strlen+1 and its bytes, NUL included)
 Packet::Packet(unsigned int istream_id, int itag, const char *ifmt, ...) : impl_(new Impl())
 {
     impl_->stream_id = istream_id; impl_->tag = itag; impl_->fmt = ifmt;
-    const std::string t = tokens(ifmt)[0];
     va_list ap;
     va_start(ap, ifmt);
-    void *arr = va_arg(ap, void *);
-    const uint64_t len = t[0] == 'A' ? va_arg(ap, uint64_t) : (uint64_t)va_arg(ap, unsigned);
-    va_end(ap);
-    impl_->array = arr; impl_->array_len = len; impl_->array_of_strings = t.substr(1) == "s";
-    impl_->buf.insert(impl_->buf.end(), (const char *)&len, (const char *)&len + 8);
-    if (impl_->array_of_strings) {
-        for (uint64_t j = 0; j < len; j++) {
-            const char *str = ((char **)arr)[j];
-            const uint32_t l = (uint32_t)strlen(str) + 1;
-            impl_->buf.insert(impl_->buf.end(), (const char *)&l, (const char *)&l + 4);
-            impl_->buf.insert(impl_->buf.end(), str, str + l);
+    for (const std::string &t : tokens(ifmt)) {
+        void *arr = va_arg(ap, void *);
+        const uint64_t len = t[0] == 'A' ? va_arg(ap, uint64_t) : (uint64_t)va_arg(ap, unsigned);
+        const bool strs = t.substr(1) == "s";
+        if (!impl_->array) { impl_->array = arr; impl_->array_len = len; impl_->array_of_strings = strs; }
+        impl_->buf.insert(impl_->buf.end(), (const char *)&len, (const char *)&len + 8);
+        if (strs) {
+            for (uint64_t j = 0; j < len; j++) {
+                const char *str = ((char **)arr)[j];
+                const uint32_t l = (uint32_t)strlen(str) + 1;
+                impl_->buf.insert(impl_->buf.end(), (const char *)&l, (const char *)&l + 4);
+                impl_->buf.insert(impl_->buf.end(), str, str + l);
+            }
+        } else {
+            impl_->buf.insert(impl_->buf.end(), (const char *)arr, (const char *)arr + len * token_width(t.substr(1)));
         }
-    } else {
-        impl_->buf.insert(impl_->buf.end(), (const char *)arr, (const char *)arr + len * token_width(t.substr(1)));
     }
+    va_end(ap);
 }
 void Packet::set_DestroyData(bool b) { impl_->destroy = b; }
 Packet::~Packet()
@@ -230,7 +232,7 @@ template <typename T> static void test_concat(const char *fmt, uint64_t n, int o
     mrpdr_ArrayConcat(in, out2, rev, &state, params, *info);
     ok = ok && out2.size() == 1 && out2[0]->get_BufferLen() == out[0]->get_BufferLen() &&
          !memcmp(out2[0]->get_Buffer(), out[0]->get_Buffer(), (size_t)out[0]->get_BufferLen());
-    release_concat(static_cast<ConcatState *>(state));
+    release_var(static_cast<VarState *>(state));
     end_SubTest(std::string("mrpdr_ArrayConcat(") + fmt + ", " + std::to_string(n) + " packets, orders " +
                 (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
 }
@@ -267,8 +269,65 @@ static void test_concat_strings(uint64_t n, int order_mode)
         want.insert(want.end(), str.c_str(), str.c_str() + l);
     }
     const bool ok = out.size() == 1 && out[0]->get_BufferLen() == want.size() && !memcmp(out[0]->get_Buffer(), want.data(), want.size());
-    release_concat(static_cast<ConcatState *>(state));
+    release_var(static_cast<VarState *>(state));
     end_SubTest(std::string("mrpdr_ArrayConcat(%as, ") + std::to_string(n) + " packets, orders " +
+                (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
+}
+
+// ---- mrpdr_IntEqClass ---------------------------------------------------------------------------
+#include <map>
+
+static void test_eq_class(uint64_t n, int order_mode)
+{
+    std::vector<PacketPtr> in, out, rev;
+    std::map<unsigned, std::vector<unsigned> > classes;          // the reference's own structure (:820, :844)
+    uint64_t x = 4242 + n * 3 + (uint64_t)order_mode;
+    for (uint64_t i = 0; i < n; i++) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const unsigned nv = (unsigned)((x >> 20) % 4);
+        std::vector<unsigned> vals(nv), cnts(nv), mems;
+        for (unsigned j = 0; j < nv; j++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            vals[j] = (unsigned)((x >> 9) % 37);
+            cnts[j] = (unsigned)((x >> 30) % 4);                  // empty classes among them
+            for (unsigned k = 0; k < cnts[j]; k++) { mems.push_back((unsigned)(i * 16 + j * 4 + k)); classes[vals[j]].push_back(mems.back()); }
+        }
+        const int bo = order_mode == 2 ? (int)(i % 3 == 1) : order_mode;
+        PacketPtr p(new Packet(11u, 3, "%aud %aud %aud", vals.data(), nv, cnts.data(), nv, mems.data(), (unsigned)mems.size()));
+        if (bo) {          // as a big-endian sender wrote it: counts and elements reversed
+            std::vector<char> &b = p->impl_->buf;
+            size_t at = 0;
+            for (int f = 0; f < 3; f++) {
+                uint64_t len; memcpy(&len, &b[at], 8);
+                for (size_t k = 0; k < 4; k++) std::swap(b[at + k], b[at + 7 - k]);
+                at += 8;
+                for (uint64_t j = 0; j < len; j++, at += 4) { std::swap(b[at], b[at + 3]); std::swap(b[at + 1], b[at + 2]); }
+            }
+        }
+        p->impl_->hdr.assign(16 + 15 + 8 + 1, 0);
+        p->impl_->hdr.back() = (char)bo;
+        in.push_back(p);
+    }
+    void *state = NULL;
+    PacketPtr params;
+    MRN::TopologyLocalInfo here, *info = &here;
+    mrpdr_IntEqClass(in, out, rev, &state, params, *info);
+    std::vector<unsigned> wv, wc, wm;
+    for (std::map<unsigned, std::vector<unsigned> >::iterator it = classes.begin(); it != classes.end(); ++it) {
+        wv.push_back(it->first); wc.push_back((unsigned)it->second.size());
+        wm.insert(wm.end(), it->second.begin(), it->second.end());
+    }
+    std::vector<char> want;
+    const std::vector<unsigned> *parts[3] = { &wv, &wc, &wm };
+    for (int f = 0; f < 3; f++) {
+        const uint64_t len = parts[f]->size();
+        want.insert(want.end(), (const char *)&len, (const char *)&len + 8);
+        want.insert(want.end(), (const char *)parts[f]->data(), (const char *)parts[f]->data() + 4 * len);
+    }
+    const bool ok = out.size() == 1 && out[0]->get_StreamId() == 11u && out[0]->get_Tag() == 3 &&
+                    out[0]->get_BufferLen() == want.size() && !memcmp(out[0]->get_Buffer(), want.data(), want.size());
+    release_var(static_cast<VarState *>(state));
+    end_SubTest(std::string("mrpdr_IntEqClass(") + std::to_string(n) + " packets, orders " +
                 (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
 }
 
@@ -293,6 +352,8 @@ int main()
             test_concat<int64_t>("%Ald", n, mode);
             test_concat_strings(n, mode);
         }
+    for (uint64_t n : { (uint64_t)1, (uint64_t)7, (uint64_t)1025, (uint64_t)20000 })
+        for (int mode = 0; mode < 3; mode++) test_eq_class(n, mode);
     {   // a scalar format is not an array: nothing comes out (src/FilterDefinitions.C:764-768)
         std::vector<PacketPtr> in, out, rev;
         int32_t a = 1;
@@ -302,7 +363,7 @@ int main()
         PacketPtr params;
         MRN::TopologyLocalInfo here, *info = &here;
         mrpdr_ArrayConcat(in, out, rev, &state, params, *info);
-        release_concat(static_cast<ConcatState *>(state));
+        release_var(static_cast<VarState *>(state));
         end_SubTest("mrpdr_ArrayConcat refuses a scalar format", out.empty());
     }
     // a format the built-ins refuse, and a wave whose packets do not share one format: no output
