@@ -1067,6 +1067,16 @@ extern "C" int32_t mrpdr_wave_decode_headers(mrpdr_ctx *c, const mrpdr_fmt *f, u
     return 1;
 }
 
+#ifdef MRPDR_TILE_STAMPS
+// diagnostic build: where the tile kernels note their phase boundaries (8 x u64 per workgroup), or NULL
+extern "C" int32_t mrpdr_debug_tile_stamps(void *buffer)
+{
+    unsigned long long *p = (unsigned long long *)buffer;
+    HIP_OK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), &p, sizeof p));
+    return 1;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // message framing
 // ---------------------------------------------------------------------------

@@ -47,6 +47,15 @@ static_assert(TILE_IMG % (MRPDR_TPB * 16) == 0 && TILE_IMG_WIDE % (MRPDR_TPB * 1
               "the image is a whole number of workgroup-wide rows of 16-byte pieces");
 static_assert(TILE_PKTS == 64, "the tile kernels give every packet of a tile one lane of a wavefront");
 
+// Diagnostic build only (tools/tile_stamps.py builds the library with -DMRPDR_TILE_STAMPS): lane 0 of
+// every workgroup notes the 100 MHz wall clock at the phase boundaries of the tile kernels.
+#ifdef MRPDR_TILE_STAMPS
+__device__ unsigned long long *g_tile_stamps;
+#define TILE_STAMP(k) do { if (threadIdx.x == 0 && g_tile_stamps) g_tile_stamps[(uint64_t)blockIdx.x * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define TILE_STAMP(k) do { } while (0)
+#endif
+
 struct TileVars {                       // the variable fields of the format, in order
     int32_t nv;
     int32_t field[TILE_MAXV];
@@ -91,9 +100,16 @@ __device__ __forceinline__ void st16_u(uint8_t *p, u32x4 v)
 // in one round of global loads; decides whether the tile can be staged.
 // With CAPS the capacities of the values columns are checked against the wave's totals in the
 // same round (offs[n] of every variable field).
-template <bool SEGS, bool CAPS, int IMG, typename L>
+struct TileNothing { __device__ __forceinline__ void operator()() const {} };
+
+// after_loads(): called when the round's loads have arrived and are on their way into LDS, before the
+// barriers and the checks: loads issued there are in flight while the boundaries are checked.  (Issued
+// any earlier they would sit in front of nothing -- loads return in issue order -- but the compiler
+// has to wait for ALL loads where a conditional one may or may not have been issued.)
+template <bool SEGS, bool CAPS, int IMG, typename L, typename F = TileNothing>
 __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const WireDev &wire,
-                                               const ColsDev &cols, uint64_t p0, uint32_t np, uint64_t n)
+                                               const ColsDev &cols, uint64_t p0, uint32_t np, uint64_t n,
+                                               F after_loads = F())
 {
     const uint32_t t = threadIdx.x;
     if (t == 0) { m.staged = 1; m.packed = 1; m.too_small = 0; }
@@ -119,6 +135,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
         for (int v = 0; v < L::NV; v++)
             if (v < tv.nv && t <= np) m.seg[v][t] = sg[v];
     }
+    after_loads();
     __syncthreads();
     if (t < np) {
         const uint64_t s = m.start[t], e = m.end[t];
@@ -181,6 +198,42 @@ __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase
         if (o < bytes) *reinterpret_cast<u32x4 *>(img + o) = x[k];
     }
 }
+
+// The same in two steps, so that the loads can be on their way while something else is done: the
+// tile's byte range needs only the first packet's start and the last packet's end (two uniform
+// loads), not the checked boundaries of all 64 -- reading the range early is harmless even if the
+// tile then turns out not to be stageable.
+template <int IMG> struct TileStage {
+    static constexpr int PIECES = IMG / (MRPDR_TPB * 16);
+    u32x4 x[PIECES];
+    uint32_t bytes;                     // 0: nothing was loaded
+    __device__ __forceinline__ void issue(const WireDev &wire, uint64_t p0, uint32_t np)
+    {
+        const uint64_t lo = wire.offsets[p0], last_at = wire.offsets[p0 + np - 1], last_len = wire.lens[p0 + np - 1];
+        const bool fine = lo <= last_at && last_at <= wire.bytes && last_len <= wire.bytes - last_at &&
+                          last_at + last_len - lo + 32 <= IMG;
+        bytes = 0;
+        if (!fine) return;              // (uniform)
+        const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
+        bytes = (uint32_t)(last_at + last_len - lo) + mis;
+        if (bytes == 0) return;
+        const uint8_t *g = wire.base + lo - mis;
+        const uint32_t last = (bytes - 1u) & ~15u;
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+            x[k] = *reinterpret_cast<const u32x4 *>(g + (o < last ? o : last));
+        }
+    }
+    __device__ __forceinline__ void commit(uint8_t *img) const
+    {
+#pragma unroll
+        for (int k = 0; k < PIECES; k++) {
+            const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+            if (o < bytes) *reinterpret_cast<u32x4 *>(img + o) = x[k];
+        }
+    }
+};
 
 // Payload of variable field v between the image (or the arena) and the values column, packet by
 // packet: 16 lanes take one packet -- 128-bit pieces while they fit, then the last few elements
@@ -399,6 +452,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     // The payload of the first variable field starts at a fixed place in every packet (only
     // scalars lie in front of it), so its loads need nothing but the tile's offs[]: they are
     // issued first and are on their way while the scalars are handled.
+    TILE_STAMP(1);
     TileFill fill;
     const uint8_t *dense0 = nullptr;
     if (STAGED && tv.nv > 0) {
@@ -438,8 +492,11 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
         tile_copy_fields<false, true, false>(m, img, fmt, tv, wire, cols, np);
         return;
     }
+    TILE_STAMP(2);
     if (tv.nv > 0) fill.store(img, dense0);
+    TILE_STAMP(3);
     __syncthreads();                     // the positions of the other variable fields are in LDS
+    TILE_STAMP(4);
     for (int v = 1; v < tv.nv; v++) {
         const int f = tv.field[v];
         const uint8_t *dense = reinterpret_cast<const uint8_t *>(cols.values[f]);
@@ -447,7 +504,9 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
                   [&m, v](uint32_t k) { return m.vpos[v][k]; });
         fill.store(img, dense);
     }
+    TILE_STAMP(5);
     __syncthreads();
+    TILE_STAMP(6);
     // image -> arena, packet by packet (16 lanes each): the bytes in front of the first 16-byte
     // boundary and behind the last one go out one per lane, the pieces between them as aligned
     // 128-bit stores.  Only bytes of packets are written: what lies between packets is not ours
@@ -464,6 +523,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
                 *reinterpret_cast<u32x4 *>(wire.base + x) = *reinterpret_cast<const u32x4 *>(img + (uint32_t)(x - lo) + mis);
             if (a1 + t < hi) wire.base[a1 + t] = img[(uint32_t)(a1 - lo) + mis + t];
         }
+        TILE_STAMP(7);
         return;
     }
     // Positions relative to the tile's first byte (32 bits: a staged tile is shorter than the
@@ -508,6 +568,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
         }
         if (ra1[k] + lane < re[k]) out[ra1[k] + lane] = tb[k];
     }
+    TILE_STAMP(7);
     if (!more) return;
 #pragma unroll
     for (int k = 0; k < PK; k++)
@@ -522,6 +583,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars 
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
+    TILE_STAMP(0);
     tile_load_meta<true, false, IMG>(m, tv, wire, cols, p0, np, n);
     if (m.staged) tile_encode_body<true>(m, img, fmt, tv, wire, cols, p0, np);
     else          tile_encode_body<false>(m, img, fmt, tv, wire, cols, p0, np);
@@ -703,18 +765,20 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     const uint32_t t = threadIdx.x;
     // (lane i of every wavefront: how many leading fields of packet i are good -- loaded with the
     // boundaries, not when the scalars need it)
+    TILE_STAMP(0);
     const uint32_t good_fields = (nvalid && (t & 63u) < np) ? nvalid[p0 + (t & 63u)] : 0u;
     // a column too small for the wave, or offs[] that do not describe these packets: nothing is
     // written, the status word says so
-    tile_load_meta<true, true, IMG>(m, tv, wire, cols, p0, np, n);
+    // the image's loads go out before the boundaries are checked, and arrive while they are
+    TileStage<IMG> early;
+    tile_load_meta<true, true, IMG>(m, tv, wire, cols, p0, np, n, [&]() { early.issue(wire, p0, np); });
+    TILE_STAMP(1);
     const bool skip = m.too_small != 0;          // no payload moves (the scalar columns are still written)
     if (skip && t == 0) atomicOr(status, 1u);
     if (skip && !nvalid) return;
     const bool staged = m.staged != 0;
-    if (staged) {
-        const uint64_t lo = m.start[0];
-        tile_stage_in<IMG>(img, wire.base, lo, m.end[np - 1], (uint32_t)((uintptr_t)(wire.base + lo) & 15u));
-    }
+    if (staged) early.commit(img);               // (a staged tile passed the same tests on the same two packets)
+    TILE_STAMP(2);
     // where every variable field starts in its packet, from the counts (a packet that failed
     // has zero counts from the failed field on, so nothing of it is moved)
     {
@@ -725,7 +789,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
             if (i < np) m.vpos[v][i] = fmt.f[f].fixed_before + tile_var_before(m, tv, fmt, f, i);
         }
     }
+    TILE_STAMP(3);
     __syncthreads();
+    TILE_STAMP(4);
     if (nvalid) {
         // scalars: one wavefront per field, one lane per packet (the field's width and column
         // come from scalar loads, the column stores of a wavefront are one contiguous run)
@@ -749,9 +815,11 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
             st_w(reinterpret_cast<uint8_t *>(cols.values[f]) + (p0 + i) * fd.width, (int)fd.width, x);
         }
     }
+    TILE_STAMP(5);
     if (skip) return;
     if (staged) tile_copy_fields<true, false, SWAP>(m, img, fmt, tv, wire, cols, np);
     else        tile_copy_fields<false, false, SWAP>(m, img, fmt, tv, wire, cols, np);
+    TILE_STAMP(6);
 }
 
 
