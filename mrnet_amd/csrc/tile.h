@@ -38,14 +38,19 @@
 #include "rows.h"
 #include "scan.h"
 
+#ifndef TILE_PKTS
 #define TILE_PKTS 64                   // measured: 32-packet tiles are 25-45 % slower
+#endif
+#ifndef TILE_TPB
+#define TILE_TPB MRPDR_TPB             // threads per workgroup of the tile kernels
+#endif
 #define TILE_MAXV 8
-#define TILE_IMG (24 * 1024)           // the LDS image of a tile: five workgroups per CU
-#define TILE_IMG_WIDE (32 * 1024)      // for waves whose 64-packet spans are longer (four per CU)
+#define TILE_IMG (TILE_PKTS * 384)      // the LDS image of a tile: 24 KiB, five workgroups per CU
+#define TILE_IMG_WIDE (TILE_PKTS * 512) // for waves whose 64-packet spans are longer: 32 KiB, four per CU
 #define TILE_OFFS_PKTS 1024            // packets per workgroup of k_tile_offs
-static_assert(TILE_IMG % (MRPDR_TPB * 16) == 0 && TILE_IMG_WIDE % (MRPDR_TPB * 16) == 0,
+static_assert(TILE_IMG % (TILE_TPB * 16) == 0 && TILE_IMG_WIDE % (TILE_TPB * 16) == 0,
               "the image is a whole number of workgroup-wide rows of 16-byte pieces");
-static_assert(TILE_PKTS == 64, "the tile kernels give every packet of a tile one lane of a wavefront");
+static_assert(TILE_PKTS <= 64 && TILE_PKTS * 4 == TILE_TPB, "a lane of a wavefront per packet; sixteen lanes move a packet, four packets each");
 
 // Diagnostic build only (tools/tile_stamps.py builds the library with -DMRPDR_TILE_STAMPS): lane 0 of
 // every workgroup notes the 100 MHz wall clock at the phase boundaries of the tile kernels.
@@ -114,8 +119,8 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
     const uint32_t t = threadIdx.x;
     if (t == 0) { m.staged = 1; m.packed = 1; m.too_small = 0; }
     bool over = false;
-    if (CAPS && t >= MRPDR_TPB - TILE_MAXV && (int)(t - (MRPDR_TPB - TILE_MAXV)) < tv.nv) {
-        const int f = tv.field[t - (MRPDR_TPB - TILE_MAXV)];
+    if (CAPS && t >= TILE_TPB - TILE_MAXV && (int)(t - (TILE_TPB - TILE_MAXV)) < tv.nv) {
+        const int f = tv.field[t - (TILE_TPB - TILE_MAXV)];
         over = cols.offs[f][n] > cols.cap[f];
     }
     // every load of the round is issued before the first LDS store waits for one of them
@@ -173,13 +178,13 @@ __device__ __forceinline__ uint64_t tile_var_before(const L &m, const TileVars &
 
 // Copy of the tile's wire range into the image: aligned 128-bit pieces (the few bytes in front
 // of the first packet and behind the last one that share their 16-byte granule come along).
-// A lane has at most IMG / (MRPDR_TPB * 16) = 6 (or 8) pieces; their loads are all issued before
+// A lane has at most IMG / (TILE_TPB * 16) = 6 (or 8) pieces; their loads are all issued before
 // the first LDS store, so the lane waits for memory once, not once per piece.  (As compiled
 // before, load - wait - store per piece, a 19 KiB tile cost five round trips in a row.)
 template <int IMG>
 __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase, uint64_t lo, uint64_t hi, uint32_t mis)
 {
-    constexpr int PIECES = IMG / (MRPDR_TPB * 16);
+    constexpr int PIECES = IMG / (TILE_TPB * 16);
     const uint8_t *g = gbase + lo - mis;
     const uint32_t bytes = (uint32_t)(hi - lo) + mis;          // at most IMG - 16 (see tile_load_meta)
     if (bytes == 0) return;
@@ -189,12 +194,12 @@ __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase
     u32x4 x[PIECES];
 #pragma unroll
     for (int k = 0; k < PIECES; k++) {
-        const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+        const uint32_t o = ((uint32_t)k * TILE_TPB + threadIdx.x) * 16u;
         x[k] = *reinterpret_cast<const u32x4 *>(g + (o < last ? o : last));
     }
 #pragma unroll
     for (int k = 0; k < PIECES; k++) {
-        const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+        const uint32_t o = ((uint32_t)k * TILE_TPB + threadIdx.x) * 16u;
         if (o < bytes) *reinterpret_cast<u32x4 *>(img + o) = x[k];
     }
 }
@@ -204,7 +209,7 @@ __device__ __forceinline__ void tile_stage_in(uint8_t *img, const uint8_t *gbase
 // loads), not the checked boundaries of all 64 -- reading the range early is harmless even if the
 // tile then turns out not to be stageable.
 template <int IMG> struct TileStage {
-    static constexpr int PIECES = IMG / (MRPDR_TPB * 16);
+    static constexpr int PIECES = IMG / (TILE_TPB * 16);
     u32x4 x[PIECES];
     uint32_t bytes;                     // 0: nothing was loaded
     __device__ __forceinline__ void issue(const WireDev &wire, uint64_t p0, uint32_t np)
@@ -221,7 +226,7 @@ template <int IMG> struct TileStage {
         const uint32_t last = (bytes - 1u) & ~15u;
 #pragma unroll
         for (int k = 0; k < PIECES; k++) {
-            const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+            const uint32_t o = ((uint32_t)k * TILE_TPB + threadIdx.x) * 16u;
             x[k] = *reinterpret_cast<const u32x4 *>(g + (o < last ? o : last));
         }
     }
@@ -229,7 +234,7 @@ template <int IMG> struct TileStage {
     {
 #pragma unroll
         for (int k = 0; k < PIECES; k++) {
-            const uint32_t o = ((uint32_t)k * MRPDR_TPB + threadIdx.x) * 16u;
+            const uint32_t o = ((uint32_t)k * TILE_TPB + threadIdx.x) * 16u;
             if (o < bytes) *reinterpret_cast<u32x4 *>(img + o) = x[k];
         }
     }
@@ -273,7 +278,7 @@ __device__ __forceinline__ void tile_copy_run(uint8_t *w, uint8_t *d, uint64_t l
 // pointers: the accesses then compile to LDS and global instructions (pointers that pass
 // through an array of generic pointers end up as flat accesses).
 struct TileFill {
-    static constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
+    static constexpr int PK = TILE_PKTS / (TILE_TPB / 16);      // packets per 16-lane group
     uint32_t wo[PK];
     uint64_t dof[PK];
     uint32_t len[PK];
@@ -290,7 +295,7 @@ struct TileFill {
         more = false;
 #pragma unroll
         for (int k = 0; k < PK; k++) {
-            const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
+            const uint32_t i = g + (uint32_t)k * (TILE_TPB / 16);
             len[k] = 0; wo[k] = 0; dof[k] = 0;
             if (i < np) {
                 const uint64_t s_lo = m.seg[v][i] * width;
@@ -343,7 +348,7 @@ __device__ __forceinline__ void tile_drain_field(L &m, const uint8_t *img, int v
                                                  uint32_t np, uint64_t lo, uint32_t mis)
 {
     typedef typename UIntOf<W>::type U;
-    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);      // packets per 16-lane group
+    constexpr int PK = TILE_PKTS / (TILE_TPB / 16);      // packets per 16-lane group
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
     uint32_t wo[PK];
     uint64_t dof[PK];
@@ -351,7 +356,7 @@ __device__ __forceinline__ void tile_drain_field(L &m, const uint8_t *img, int v
     bool more = false;
 #pragma unroll
     for (int k = 0; k < PK; k++) {
-        const uint32_t i = g + (uint32_t)k * (MRPDR_TPB / 16);
+        const uint32_t i = g + (uint32_t)k * (TILE_TPB / 16);
         len[k] = 0; wo[k] = 0; dof[k] = 0;
         if (i < np) {
             const uint64_t s_lo = m.seg[v][i] * W;
@@ -404,7 +409,7 @@ __device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDe
         return;
     }
     const uint32_t g = threadIdx.x >> 4, lane = threadIdx.x & 15u;
-    for (uint32_t i = g; i < np; i += MRPDR_TPB / 16) {
+    for (uint32_t i = g; i < np; i += TILE_TPB / 16) {
         const uint64_t s_lo = m.seg[v][i] * W, len = m.seg[v][i + 1] * W - s_lo;
         if (len == 0 || (!STAGED && len >= TILE_BIG_PAYLOAD)) continue;
         tile_copy_run<16u, STAGED, ENCODE, SWAP, W>(
@@ -414,7 +419,7 @@ __device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDe
     for (uint32_t i = 0; i < np; i++) {
         const uint64_t s_lo = m.seg[v][i] * W, len = m.seg[v][i + 1] * W - s_lo;
         if (len < TILE_BIG_PAYLOAD) continue;
-        tile_copy_run<MRPDR_TPB, STAGED, ENCODE, SWAP, W>(
+        tile_copy_run<TILE_TPB, STAGED, ENCODE, SWAP, W>(
             tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + m.vpos[v][i] + pre), dense + s_lo, len, threadIdx.x);
     }
 }
@@ -468,12 +473,12 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
     const uint32_t i = t & 63u;
     // where every variable field starts in its packet
-    for (int v = wv; v < tv.nv; v += MRPDR_TPB / 64) {
+    for (int v = wv; v < tv.nv; v += TILE_TPB / 64) {
         const int f = tv.field[v];
         if (i < np) m.vpos[v][i] = fmt.f[f].fixed_before + tile_var_before(m, tv, fmt, f, i);
     }
     // scalars and length prefixes
-    for (int f = wv; f < fmt.nf; f += MRPDR_TPB / 64) {
+    for (int f = wv; f < fmt.nf; f += TILE_TPB / 64) {
         const FieldDev fd = fmt.f[f];
         if (i >= np) continue;
         uint8_t *dst = tile_at<STAGED>(img, wire.base, lo, mis, m.start[i] + fd.fixed_before + tile_var_before(m, tv, fmt, f, i));
@@ -519,7 +524,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
         if (lo + t < head_end) wire.base[lo + t] = img[mis + t];
         if (a0 < hi) {
             const uint64_t a1 = a0 + ((hi - a0) & ~(uint64_t)15);
-            for (uint64_t x = a0 + (uint64_t)t * 16u; x < a1; x += MRPDR_TPB * 16u)
+            for (uint64_t x = a0 + (uint64_t)t * 16u; x < a1; x += TILE_TPB * 16u)
                 *reinterpret_cast<u32x4 *>(wire.base + x) = *reinterpret_cast<const u32x4 *>(img + (uint32_t)(x - lo) + mis);
             if (a1 + t < hi) wire.base[a1 + t] = img[(uint32_t)(a1 - lo) + mis + t];
         }
@@ -530,7 +535,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     // image); image byte of relative position r is img[r + mis], and r + mis has the alignment
     // of the arena address.  The LDS reads of a lane's four packets are issued before the first
     // global store.
-    constexpr int PK = TILE_PKTS / (MRPDR_TPB / 16);
+    constexpr int PK = TILE_PKTS / (TILE_TPB / 16);
     const uint32_t grp = t >> 4, lane = t & 15u;
     uint8_t *out = wire.base + lo;
     const uint8_t *src = img + mis;
@@ -538,7 +543,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
     bool more = false;
 #pragma unroll
     for (int k = 0; k < PK; k++) {
-        const uint32_t i = grp + (uint32_t)k * (MRPDR_TPB / 16);
+        const uint32_t i = grp + (uint32_t)k * (TILE_TPB / 16);
         rs[k] = re[k] = 0;
         if (i < np) { rs[k] = (uint32_t)(m.start[i] - lo); re[k] = (uint32_t)(m.end[i] - lo); }
         ra0[k] = rs[k] + ((0u - (rs[k] + mis)) & 15u);          // first 16-byte boundary at or behind the start
@@ -577,7 +582,7 @@ __device__ __forceinline__ void tile_encode_body(L &m, uint8_t *img, const FmtDe
 }
 
 template <int V, int IMG>
-__global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols, uint64_t n)
+__global__ __launch_bounds__(TILE_TPB) void k_tile_encode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols, uint64_t n)
 {
     __shared__ TileLdsT<V> m;
     __shared__ __attribute__((aligned(16))) uint8_t img[IMG];
@@ -593,7 +598,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_encode(FmtDev fmt, TileVars 
 // decode, begin: walk
 // ---------------------------------------------------------------------------
 template <bool SWAP, int V, int IMG>
-__global__ __launch_bounds__(MRPDR_TPB) void k_tile_walk(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
+__global__ __launch_bounds__(TILE_TPB) void k_tile_walk(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                          uint64_t n, int32_t *ok, uint64_t *tile_sums,
                                                          uint64_t ntiles)
 {
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_offs(TileVars tv, ColsDev co
 // image, with k_count_walk's verdict on every packet (field f of packet i is good iff f < nvalid[i];
 // the fields behind a failure read as zero).
 template <bool SWAP, int V, int IMG>
-__global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
+__global__ __launch_bounds__(TILE_TPB) void k_tile_decode(FmtDev fmt, TileVars tv, WireDev wire, ColsDev cols,
                                                            uint64_t n, uint32_t *status, const uint8_t *nvalid)
 {
     __shared__ TileLdsT<V> m;
@@ -784,7 +789,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
     {
         const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));      // a wavefront per field
         const uint32_t i = t & 63u;
-        for (int v = wv; v < tv.nv; v += MRPDR_TPB / 64) {
+        for (int v = wv; v < tv.nv; v += TILE_TPB / 64) {
             const int f = tv.field[v];
             if (i < np) m.vpos[v][i] = fmt.f[f].fixed_before + tile_var_before(m, tv, fmt, f, i);
         }
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tile_decode(FmtDev fmt, TileVars 
         const uint32_t i = t & 63u;
         const uint64_t lo = m.start[0];
         const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
-        for (int f = wv; f < fmt.nf; f += MRPDR_TPB / 64) {
+        for (int f = wv; f < fmt.nf; f += TILE_TPB / 64) {
             const FieldDev fd = fmt.f[f];
             if (fd.kind != MRPDR_SCALAR || i >= np) continue;
             uint64_t x = 0;
