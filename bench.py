@@ -786,48 +786,55 @@ def main():
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
     if world > 1:
-        # the one exchange step of the path: a '%lf %d' wave of world x 131,072
-        # packets, fused Avg per shard, results all-gathered (RCCL) and folded in rank order
-        from mrnet_amd import dist as D
-        n5 = 131072
-        fmt5 = W.Format("%lf %d")
-        g5 = torch.Generator(device="cuda").manual_seed(5 + rank)
-        v = torch.randn(n5, dtype=torch.float64, device="cuda", generator=g5) * 1e-4 + 1e-3
-        rows = torch.empty((n5, 12), dtype=torch.uint8, device="cuda")
-        rows[:, :8] = v.view(torch.uint8).view(n5, 8)
-        rows[:, 8:] = torch.ones(n5, dtype=torch.int32, device="cuda").view(torch.uint8).view(n5, 4)
-        w5 = W.WireWave(rows.view(-1), n5, None, None, 12)
-        for _ in range(3):
-            res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
-        barrier()
-        t5 = time.perf_counter()
-        for _ in range(20):
-            res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
-        barrier()
-        t5 = (time.perf_counter() - t5) / 20
-        cnt5 = int(res5[8:12].view(torch.int32).item())
-        assert int(ok5.item()) == 1 and cnt5 == n5 * world, "sharded Avg lost packets"
-        # the same for the performance-data shape: 131,072 x '%ad %ad %alf'[8] per rank, Avg, per-rank
-        # output packets gathered (80 bytes each) and folded once more
-        k5 = 8
-        fmtp = W.Format("%ad %ad %alf")
-        onesp = np.ones(n5, np.uint64)
-        colsp = codec.columns_from_numpy(fmtp, [
-            (onesp, (np.arange(n5, dtype=np.int32) + rank * n5)), (onesp, np.full(n5, k5, np.int32)),
-            (np.full(n5, k5, np.uint64), np.random.default_rng(50 + rank).normal(1e-3, 1e-4, n5 * k5))])
-        for _ in range(3):
-            pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
-        barrier()
-        t5b = time.perf_counter()
-        for _ in range(20):
-            pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
-        barrier()
-        t5b = (time.perf_counter() - t5b) / 20
-        assert int(pl5.item()) == k5 and int(pr5.item()) == -n5 * world, "sharded PerfData lost ranks"
-        if rank == 0:
-            out["extra"] = {"c5_sharded_avg_us_per_wave": round(t5 * 1e6, 1), "c5_packets": n5 * world,
-                            "c5_avg": float(res5[:8].view(torch.float64).item()),
-                            "c5b_sharded_perfdata_avg_us_per_wave": round(t5b * 1e6, 1)}
+        # (a failure here -- the same on every rank, the inputs are seeded -- must not cost the
+        # headline line that is already measured: it is reported in the line instead)
+        try:
+            # the one exchange step of the path: a '%lf %d' wave of world x 131,072
+            # packets, fused Avg per shard, results all-gathered (RCCL) and folded in rank order
+            from mrnet_amd import dist as D
+            n5 = 131072
+            fmt5 = W.Format("%lf %d")
+            g5 = torch.Generator(device="cuda").manual_seed(5 + rank)
+            v = torch.randn(n5, dtype=torch.float64, device="cuda", generator=g5) * 1e-4 + 1e-3
+            rows = torch.empty((n5, 12), dtype=torch.uint8, device="cuda")
+            rows[:, :8] = v.view(torch.uint8).view(n5, 8)
+            rows[:, 8:] = torch.ones(n5, dtype=torch.int32, device="cuda").view(torch.uint8).view(n5, 4)
+            w5 = W.WireWave(rows.view(-1), n5, None, None, 12)
+            for _ in range(3):
+                res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(20):
+                res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
+            barrier()
+            t5 = (time.perf_counter() - t5) / 20
+            cnt5 = int(res5[8:12].view(torch.int32).item())
+            assert int(ok5.item()) == 1 and cnt5 == n5 * world, "sharded Avg lost packets"
+            # the same for the performance-data shape: 131,072 x '%ad %ad %alf'[8] per rank, Avg, per-rank
+            # output packets gathered (80 bytes each) and folded once more
+            k5 = 8
+            fmtp = W.Format("%ad %ad %alf")
+            onesp = np.ones(n5, np.uint64)
+            colsp = codec.columns_from_numpy(fmtp, [
+                (onesp, (np.arange(n5, dtype=np.int32) + rank * n5)), (onesp, np.full(n5, k5, np.int32)),
+                (np.full(n5, k5, np.uint64), np.random.default_rng(50 + rank).normal(1e-3, 1e-4, n5 * k5))])
+            for _ in range(3):
+                pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
+            barrier()
+            t5b = time.perf_counter()
+            for _ in range(20):
+                pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
+            barrier()
+            t5b = (time.perf_counter() - t5b) / 20
+            assert int(pl5.item()) == k5 and int(pr5.item()) == -n5 * world, "sharded PerfData lost ranks"
+            if rank == 0:
+                out["extra"] = {"c5_sharded_avg_us_per_wave": round(t5 * 1e6, 1), "c5_packets": n5 * world,
+                                "c5_avg": float(res5[:8].view(torch.float64).item()),
+                                "c5b_sharded_perfdata_avg_us_per_wave": round(t5b * 1e6, 1)}
+        except Exception as e:                          # noqa: BLE001
+            print("rank %d: sharded filter leg failed: %r" % (rank, e), file=sys.stderr)
+            if rank == 0:
+                out["extra_error"] = repr(e)
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
