@@ -291,8 +291,23 @@ __device__ inline int tile_load(const FilterIn &in, T *vals, int32_t *cnts)
     return nvalid;
 }
 
+// The last level over a wave of one tile, by the thread that holds the tile's node: the same
+// fold as tree_top over one staged node, so a wave of up to FILTER_TILE packets needs no second
+// launch (the reference's own microbenchmark wave has four packets).
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Partial *partials)
+__device__ inline void top_of_one(const Partial &node, uint8_t *result, int32_t *result_ok)
+{
+    Folder<OP, T> g;
+    g.init();
+    if (node.present) g.add(from_bits<T>(node.bits), node.cnt);
+    const bool present = g.finish_top();
+    write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
+}
+
+// result != NULL: the launch has one workgroup and writes the filter's result itself.
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Partial *partials, uint8_t *result,
+                                                                int32_t *result_ok)
 {
     __shared__ Partial wave_part[MRPDR_TPB / 64];
     T vals[FILTER_LEAF];
@@ -306,7 +321,9 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_tile(FilterIn in, Par
         for (int k = 0; k < FILTER_LEAF; k++) cnts[k] = vals[k] != vals[k];
     }
     const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
-    if (threadIdx.x == 0) partials[blockIdx.x] = out;
+    if (threadIdx.x != 0) return;
+    if (result) top_of_one<OP, T>(out, result, result_ok);
+    else partials[blockIdx.x] = out;
 }
 
 // One lane folds m staged nodes in order.  Eight LDS reads are issued before the first of them is

@@ -6,7 +6,7 @@
 // are read twice and the wave costs three launches (rows -> columns; columns -> tree nodes; nodes
 // -> result).  Here a workgroup stages its 1,024 rows in LDS once, writes the columns AND folds the
 // first field (with the int32 count behind it for AVG) into its tree node; the last level is the
-// filter's own second launch.  Lane t takes rows 4t .. 4t+3 -- the leaf of the declared tree -- so
+// filter's own second launch (a wave of one tile takes it in the same launch).  Lane t takes rows 4t .. 4t+3 -- the leaf of the declared tree -- so
 // the nodes, and with them the result, are those of mrpdr_wave_filter over the decoded column, bit
 // for bit, for the tree shape and for every flat result that is computed level by level.
 #pragma once
@@ -36,7 +36,8 @@ __device__ __forceinline__ uint64_t fused_field(const uint8_t *row, uint32_t at,
 
 template <int OP, typename T>
 __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode_filter(FmtDev fmt, WireDev wire, ColsDev cols, uint64_t n,
-                                                                  int32_t swap, int32_t *ok, Partial *partials)
+                                                                  int32_t swap, int32_t *ok, Partial *partials,
+                                                                  uint8_t *result, int32_t *result_ok)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     __shared__ Partial wave_part[MRPDR_TPB / 64];
@@ -99,5 +100,8 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_rows_decode_filter(FmtDev fmt, Wi
         for (int k = 0; k < FILTER_LEAF; k++) cnts[k] = vals[k] != vals[k];
     }
     const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
-    if (threadIdx.x == 0) partials[blockIdx.x] = out;
+    if (threadIdx.x != 0) return;
+    // (result != NULL: the wave is this one tile, and the last level is taken here)
+    if (result) top_of_one<OP, T>(out, result, result_ok);
+    else partials[blockIdx.x] = out;
 }

@@ -1183,8 +1183,13 @@ template <int OP, typename T>
 static int32_t run_tree(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
 {
     const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
+    if (tiles == 1) {           // one tile: its workgroup takes the last level too
+        k_filter_tree_tile<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, partials, result, result_ok);
+        LAUNCHED("k_filter_tree_tile");
+        return 1;
+    }
     if (tiles) {
-        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, partials);
+        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, partials, nullptr, nullptr);
         LAUNCHED("k_filter_tree_tile");
     }
     k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(partials, tiles, result, result_ok);
@@ -1325,7 +1330,14 @@ static int32_t launch_fused(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev &wd,
                             int32_t swap, int32_t *ok, uint8_t *result, int32_t *result_ok, hipStream_t st)
 {
     const uint32_t tiles = blocks_for(n, FILTER_TILE);
-    k_rows_decode_filter<OP, T><<<tiles, MRPDR_TPB, FILTER_TILE * wd.stride, st>>>(f->dev, wd, cd, n, swap, ok, c->partials);
+    if (tiles == 1) {           // one tile: its workgroup takes the last level too
+        k_rows_decode_filter<OP, T><<<1, MRPDR_TPB, FILTER_TILE * wd.stride, st>>>(f->dev, wd, cd, n, swap, ok, c->partials,
+                                                                                    result, result_ok);
+        LAUNCHED("k_rows_decode_filter");
+        return 1;
+    }
+    k_rows_decode_filter<OP, T><<<tiles, MRPDR_TPB, FILTER_TILE * wd.stride, st>>>(f->dev, wd, cd, n, swap, ok, c->partials,
+                                                                                    nullptr, nullptr);
     LAUNCHED("k_rows_decode_filter");
     k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(c->partials, tiles, result, result_ok);
     LAUNCHED("k_filter_tree_top");
