@@ -278,6 +278,18 @@ def filter_flat(op, t, vals, cnt=None):
     return out[0], oc.value
 
 
+def bench_small_wave(reps, value=1):
+    """Seconds per wave of the 4-packet '%d' decode + Sum + encode loop, timed inside the C library."""
+    fn = lib().orc_bench_small_wave
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
+    s = C.c_int32(0)
+    t = fn(reps, value, C.byref(s))
+    if t < 0 or s.value != 4 * value:
+        raise RuntimeError("orc_bench_small_wave failed")
+    return t
+
+
 def filter_tree(op, t, vals, cnt, fanin):
     vals = np.ascontiguousarray(vals, dtype=elem_dtype(t))
     if cnt is not None:

@@ -204,6 +204,15 @@ int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts
                                 uint64_t n, uint32_t *out_vals, uint32_t *out_memcnts, uint32_t *out_mems,
                                 uint64_t *nclasses, uint64_t *nmems);
 
+/* ---- timing helper (bench.py's CPU baseline leg) ----------------------------------- */
+/*
+ * What one node of the reference's microbenchmark tree does per wave (tests/microbench_FE.C:61,145,
+ * over tests/topology_files/local-1x4.top): four "%d" packets decoded, tfilter_Sum, the one output
+ * packet encoded -- `reps` times in a C loop, so that no foreign-function call is in the figure.
+ * Returns seconds per wave; *sum receives the last result (4 x value).
+ */
+double orc_bench_small_wave(uint64_t reps, int32_t value, int32_t *sum);
+
 #ifdef __cplusplus
 }
 #endif
