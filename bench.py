@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 from mrnet_amd import wave as W  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak
+SWEEP_SIZES = (4, 64, 1024, 16384, 65536)      # packets per wave of the node-wave sweep (GPU and CPU legs)
 
 
 def parse():
@@ -235,8 +236,11 @@ def cpu_baseline(n, m, reps):
     assert int(e1.view(np.int32)[0]) == 4
     # the figure above is mostly Python and foreign-function calls; the same loop inside the C library
     c1_us = O.bench_small_wave(200000) * 1e6
+    # and for growing waves of the same kind (a tree node with n children: decode n x '%d', Sum, encode one)
+    sweep = {str(n): round(O.bench_small_wave(max(10, 200000 // n), n) * 1e6, 2) for n in SWEEP_SIZES}
     return {"value": round(nbytes / best[0] / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "c1_us_per_wave": round(c1_us, 2), "c1_us_per_wave_via_ctypes": round(c1_ctypes_us, 2),
+            "node_wave_us_by_packets": sweep,
             "sample": "%d packets x '%%af'[%d] (%.0f MiB of data), decode big-endian + sizeof + encode, "
                       "best of %d, decode %.2f s encode %.2f s" % (n, m, data / 2**20, reps, best[1], best[2]),
             "all_cores": {"value": round(nbytes / t_all / 1e9, 3), "unit": "GB/s", "cores": cores,
@@ -292,6 +296,22 @@ def small_wave_extras(codec):
         torch.cuda.synchronize()
     out["c1_us_per_wave_host_waits"] = round(time_call(c1_latency, 500) * 1e6, 2)
     assert int(res[:4].view(torch.int32).item()) == 4
+    # the same node work for growing waves (n children): where the device starts to pay.  Two figures
+    # each: calls streamed back to back, and with the host waiting for every result (what a node
+    # that forwards one wave at a time sees).  The CPU leg reports the oracle's figure for the same n.
+    sweep = {}
+    for ns in SWEEP_SIZES:
+        ws = W.WireWave(torch.ones(ns, dtype=torch.int32, device=dev).view(torch.uint8), ns, None, None, 4)
+        cs, oks = codec.alloc_columns(fmt, ns), torch.empty(ns, dtype=torch.int32, device=dev)
+        call = codec.bind_decode_filter(fmt, ws, cs, oks, W.TFILTER_SUM, W.SHAPE_FLAT, res, rok)
+
+        def call_wait():
+            call()
+            torch.cuda.synchronize()
+        sweep[str(ns)] = {"streamed": round(time_call(call, 300) * 1e6, 2),
+                          "host_waits": round(time_call(call_wait, 300) * 1e6, 2)}
+        assert int(res[:4].view(torch.int32).item()) == ns
+    out["node_wave_us_by_packets"] = sweep
     # what ONE reference filter call (the flat shape, the mirrors' default) costs where the order of
     # the additions matters -- a serial chain -- beside the declared tree; 65,536 packets each
     vf = torch.randn(n, dtype=torch.float32, device=dev)

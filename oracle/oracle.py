@@ -278,14 +278,14 @@ def filter_flat(op, t, vals, cnt=None):
     return out[0], oc.value
 
 
-def bench_small_wave(reps, value=1):
-    """Seconds per wave of the 4-packet '%d' decode + Sum + encode loop, timed inside the C library."""
+def bench_small_wave(reps, n=4, value=1):
+    """Seconds per wave of the n-packet '%d' decode + Sum + encode loop, timed inside the C library."""
     fn = lib().orc_bench_small_wave
     fn.restype = C.c_double
-    fn.argtypes = [C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
+    fn.argtypes = [C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_int32)]
     s = C.c_int32(0)
-    t = fn(reps, value, C.byref(s))
-    if t < 0 or s.value != 4 * value:
+    t = fn(reps, n, value, C.byref(s))
+    if t < 0 or s.value != (n * value + 2**31) % 2**32 - 2**31:      # the int32 sum wraps
         raise RuntimeError("orc_bench_small_wave failed")
     return t
 

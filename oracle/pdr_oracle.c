@@ -1090,27 +1090,36 @@ int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts
 /* ======================================================================= */
 /* timing helper                                                           */
 /* ======================================================================= */
-double orc_bench_small_wave(uint64_t reps, int32_t value, int32_t *sum)
+double orc_bench_small_wave(uint64_t reps, uint64_t n, int32_t value, int32_t *sum)
 {
-    enum { N = 4 };
-    int32_t in[N], dec[N], ok[N], res = 0, cnt = 0;
-    uint64_t offs[N + 1], lens[N], one_off[2] = { 0, 4 }, one_len[1];
-    char arena[4 * N], out[4];
-    for (int i = 0; i < N; i++) { in[i] = value; offs[i] = 4u * (uint64_t)i; }
-    offs[N] = 4 * N;
-    orc_column src = { ORC_INT32, in, NULL, NULL, NULL, NULL };
-    if (!orc_wave_encode("%d", &src, N, offs, arena, lens)) return -1.0;
+    if (n == 0) return -1.0;
+    int32_t *in = (int32_t *)malloc(n * sizeof *in), *dec = (int32_t *)malloc(n * sizeof *dec);
+    int32_t *ok = (int32_t *)malloc(n * sizeof *ok), res = 0, cnt = 0;
+    uint64_t *offs = (uint64_t *)malloc((n + 1) * sizeof *offs), *lens = (uint64_t *)malloc(n * sizeof *lens);
+    uint64_t one_off[2] = { 0, 4 }, one_len[1];
+    char *arena = (char *)malloc(4 * n), out[4] = { 0, 0, 0, 0 };
+    double per_wave = -1.0;
+    if (!in || !dec || !ok || !offs || !lens || !arena) goto done;
+    for (uint64_t i = 0; i < n; i++) { in[i] = value; offs[i] = 4u * i; }
+    offs[n] = 4 * n;
+    {
+        orc_column src = { ORC_INT32, in, NULL, NULL, NULL, NULL };
+        if (!orc_wave_encode("%d", &src, n, offs, arena, lens)) goto done;
+    }
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (uint64_t r = 0; r < reps; r++) {
         orc_column col = { ORC_INT32, dec, NULL, NULL, NULL, NULL };
-        if (orc_wave_decode("%d", arena, offs, lens, N, orc_local_bo(), &col, ok) != N) return -1.0;
-        if (!orc_filter_flat(ORC_SUM, ORC_INT32, dec, NULL, N, &res, &cnt)) return -1.0;
+        if (orc_wave_decode("%d", arena, offs, lens, n, orc_local_bo(), &col, ok) != n) goto done;
+        if (!orc_filter_flat(ORC_SUM, ORC_INT32, dec, NULL, n, &res, &cnt)) goto done;
         orc_column o = { ORC_INT32, &res, NULL, NULL, NULL, NULL };
-        if (!orc_wave_encode("%d", &o, 1, one_off, out, one_len)) return -1.0;
+        if (!orc_wave_encode("%d", &o, 1, one_off, out, one_len)) goto done;
         __asm__ volatile("" : : "r"(out) : "memory");          /* the result is used */
     }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     memcpy(sum, out, 4);
-    return ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec)) / (double)(reps ? reps : 1);
+    per_wave = ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec)) / (double)(reps ? reps : 1);
+done:
+    free(in); free(dec); free(ok); free(offs); free(lens); free(arena);
+    return per_wave;
 }

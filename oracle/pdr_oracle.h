@@ -206,12 +206,13 @@ int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts
 
 /* ---- timing helper (bench.py's CPU baseline leg) ----------------------------------- */
 /*
- * What one node of the reference's microbenchmark tree does per wave (tests/microbench_FE.C:61,145,
- * over tests/topology_files/local-1x4.top): four "%d" packets decoded, tfilter_Sum, the one output
- * packet encoded -- `reps` times in a C loop, so that no foreign-function call is in the figure.
- * Returns seconds per wave; *sum receives the last result (4 x value).
+ * What one node of a reduction tree does per wave: n "%d" packets decoded, tfilter_Sum, the one
+ * output packet encoded -- `reps` times in a C loop, so that no foreign-function call is in the
+ * figure.  n = 4 is the reference's microbenchmark (tests/microbench_FE.C:61,145 over
+ * tests/topology_files/local-1x4.top).  Returns seconds per wave (negative on failure); *sum
+ * receives the last result (n x value, wrapping).
  */
-double orc_bench_small_wave(uint64_t reps, int32_t value, int32_t *sum);
+double orc_bench_small_wave(uint64_t reps, uint64_t n, int32_t value, int32_t *sum);
 
 #ifdef __cplusplus
 }
