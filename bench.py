@@ -308,9 +308,21 @@ def small_wave_extras(codec):
         def call_wait():
             call()
             torch.cuda.synchronize()
+        # third figure: the result written by the kernel straight into pinned host memory, the host
+        # polling result_ok there instead of synchronising the stream
+        res_h, rok_h = torch.zeros(16, dtype=torch.uint8).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory()
+        call_h = codec.bind_decode_filter(fmt, ws, cs, oks, W.TFILTER_SUM, W.SHAPE_FLAT, res_h, rok_h)
+        flag = rok_h.numpy()
+
+        def call_poll():
+            flag[0] = 0
+            call_h()
+            while flag[0] == 0:
+                pass
         sweep[str(ns)] = {"streamed": round(time_call(call, 300) * 1e6, 2),
-                          "host_waits": round(time_call(call_wait, 300) * 1e6, 2)}
-        assert int(res[:4].view(torch.int32).item()) == ns
+                          "host_waits": round(time_call(call_wait, 300) * 1e6, 2),
+                          "host_polls_pinned_result": round(time_call(call_poll, 300) * 1e6, 2)}
+        assert int(res[:4].view(torch.int32).item()) == ns and int(res_h.numpy()[:4].view(np.int32)[0]) == ns
     out["node_wave_us_by_packets"] = sweep
     # what ONE reference filter call (the flat shape, the mirrors' default) costs where the order of
     # the additions matters -- a serial chain -- beside the declared tree; 65,536 packets each

@@ -379,6 +379,30 @@ def test_fused_min_max_avg_equals_the_three_filters(codec, tok, t, dt):
             assert torch.equal(res[16 * k:16 * k + 16], one), (tok, n, op)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4, 1025, 65536])
+def test_result_written_to_pinned_host_memory(codec, n):
+    """`result` / `result_ok` may be pinned host memory: the last launch writes the output packet's
+    bytes there itself, and a node that forwards one wave at a time polls result_ok instead of
+    synchronising the stream.  Same bytes as with a device buffer, and as the oracle's fold."""
+    vals = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32, device=codec.device)
+    res_h, ok_h = torch.zeros(16, dtype=torch.uint8).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory()
+    flag = ok_h.numpy()
+    for op in (W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX):
+        res_d, ok_d = codec.filter_raw(op, W.DataType.INT32_T, vals.data_ptr(), 4, None, 0, n)
+        flag[0] = 0
+        codec.filter_raw(op, W.DataType.INT32_T, vals.data_ptr(), 4, None, 0, n, result=res_h, result_ok=ok_h)
+        spins = 0
+        while flag[0] == 0 and spins < 50_000_000:
+            spins += 1
+        assert flag[0] == 1, "the result never arrived in host memory"
+        torch.cuda.synchronize()
+        assert bytes(res_h.numpy()) == bytes(res_d.cpu().numpy())
+        want = O.filter_flat({W.TFILTER_SUM: O.SUM, W.TFILTER_MIN: O.MIN, W.TFILTER_MAX: O.MAX}[op], O.INT32_T,
+                             vals.cpu().numpy())
+        assert int(res_h.numpy()[:4].view(np.int32)[0]) == int(want[0])
+
+
 import os  # noqa: E402
 
 SOAK = max(1, int(os.environ.get("MRPDR_SOAK", "1")))
