@@ -54,6 +54,33 @@ def filter_wire_sharded(codec, op, fmt, wire, sender_bo=W.LITTLEENDIAN, group=No
     return combine_results(codec, op, fmt.types[0], fmt.widths[0], rows, oks)
 
 
+def stats_wire_sharded(codec, fmt, wire, sender_bo=W.LITTLEENDIAN, group=None):
+    """Min, Max and Avg of a '<T> %d' wave spread over the ranks of `group` (the three streams a
+    PerformanceData-style tool runs over one wave): one fused pass over this rank's shard
+    (mrpdr_wave_filter_stats, tree shape), ONE all_gather of 60 bytes per rank, then the last tree
+    level of each operator folded in rank order.  Every rank returns (uint8[48], int32[3]): the three
+    16-byte results (MIN, MAX, AVG) and their presence flags -- equal to three filter_wire_sharded
+    calls, with one exchange instead of three."""
+    if len(fmt) != 2 or not fmt.is_fixed or fmt.types[1] != W.DataType.INT32_T or wire.offsets is not None:
+        raise W.PdrError("stats_wire_sharded needs a packed '%T %d' wave")
+    base, w = wire.arena.data_ptr(), fmt.widths[0]
+    swap = int(sender_bo != W.LITTLEENDIAN)
+    res, oks = codec.filter_stats_raw(fmt.types[0], base, wire.stride, base + w, wire.stride, wire.n, swap)
+    row = torch.zeros(60, dtype=torch.uint8, device=res.device)
+    row[:48] = res
+    row[48:60] = oks.view(torch.uint8)
+    rows = gather_rows(row, group)                                   # [G, 60], rank order
+    flags = rows[:, 48:60].contiguous().view(torch.int32).view(-1, 3)
+    out = torch.zeros(48, dtype=torch.uint8, device=res.device)
+    out_ok = torch.zeros(3, dtype=torch.int32, device=res.device)
+    for k, op in enumerate((W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
+        r, ok = combine_results(codec, op, fmt.types[0], w, rows[:, 16 * k:16 * k + 16].contiguous(),
+                                flags[:, k].contiguous())
+        out[16 * k:16 * k + 16] = r
+        out_ok[k:k + 1] = ok
+    return out, out_ok
+
+
 # ---- tfilter_PerfData across ranks ---------------------------------------------------------
 # Every rank folds its shard into one output packet ([-nranks], [len], data[len]); the packets of
 # all ranks are gathered and folded once more by the same filter, in rank order -- the per-GPU

@@ -42,6 +42,15 @@ def _worker(rank, world, port, q):
         rows[:, 8:] = cnts[lo:hi].view(np.uint8).reshape(-1, 4)
         wire = W.WireWave(codec.to_device(rows.reshape(-1)), hi - lo, None, None, 12)
         res, ok = D.filter_wire_sharded(codec, W.TFILTER_AVG, W.Format("%lf %d"), wire)
+        # Min, Max and Avg with one exchange: the same bytes as three sharded filters
+        st3, ok3 = D.stats_wire_sharded(codec, W.Format("%lf %d"), wire)
+        for k, op in enumerate((W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
+            r1, o1 = D.filter_wire_sharded(codec, op, W.Format("%lf %d") if op == W.TFILTER_AVG else W.Format("%lf"),
+                                           wire if op == W.TFILTER_AVG else
+                                           W.WireWave(codec.to_device(np.ascontiguousarray(rows[:, :8]).reshape(-1)),
+                                                      hi - lo, None, None, 8))
+            assert int(o1.item()) == int(ok3[k].item()) == 1
+            assert torch.equal(r1, st3[16 * k:16 * k + 16]), "fused sharded stats differ from the sharded filter %d" % op
         rc, rv, dc, dv = _perf_wave(N, K)
         fmt = W.Format("%ad %ad %alf")
         cols = codec.columns_from_numpy(fmt, [(rc[lo:hi], rv[lo:hi]), (rc[lo:hi], np.full(hi - lo, K, np.int32)),
