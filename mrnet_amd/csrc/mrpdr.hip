@@ -675,7 +675,7 @@ static int32_t encode_phases(const char *who, mrpdr_ctx *c, const mrpdr_fmt *f, 
         bool timed;
         if (!perf_begin(c, st, &timed, 1)) return 0;
         tile_variant(f->tv.nv <= TILE_SMALLV, tile_wide(wd, n), [&](auto v, auto img) {
-            k_tile_encode<decltype(v)::value, decltype(img)::value><<<blocks_for(n, TILE_PKTS), TILE_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n);
+            k_tile_encode<decltype(v)::value, decltype(img)::value><<<blocks_for(n, TILE_PKTS), TILE_TPB, 0, st>>>(f->dev, tile_vars_of(f->tv, cd), wd, cd, n);
         });
         LAUNCHED("k_tile_encode");
         return perf_end(c, st, timed, 1);
@@ -758,8 +758,8 @@ static int32_t launch_tile_walk(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev 
     const bool wide = tile_wide(wd, n);
     tile_variant(small, wide, [&](auto v, auto img) {
         constexpr int V = decltype(v)::value, IMG = decltype(img)::value;
-        if (swap) k_tile_walk<true, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
-        else      k_tile_walk<false, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+        if (swap) k_tile_walk<true, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, tile_vars_of(f->tv, cd), wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
+        else      k_tile_walk<false, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, tile_vars_of(f->tv, cd), wd, cd, n, ok, c->tile_cnt, c->ntile_cnt);
     });
     LAUNCHED("k_tile_walk");
     return 1;
@@ -768,7 +768,7 @@ static int32_t launch_tile_walk(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDev 
 static int32_t launch_tile_offs(mrpdr_ctx *c, const mrpdr_fmt *f, const ColsDev &cd, uint64_t n, uint32_t pkts_per_sum,
                                 hipStream_t st)
 {
-    k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(f->tv, cd, n, c->tile_cnt,
+    k_tile_offs<<<dim3(blocks_for(n, TILE_OFFS_PKTS), (uint32_t)f->tv.nv), MRPDR_TPB, 0, st>>>(tile_vars_of(f->tv, cd), cd, n, c->tile_cnt,
                                                                                                  c->ntile_cnt, pkts_per_sum);
     LAUNCHED("k_tile_offs");
     return 1;
@@ -784,8 +784,8 @@ static int32_t launch_tile_decode(mrpdr_ctx *c, const mrpdr_fmt *f, const WireDe
     const bool wide = tile_wide(wd, n);
     tile_variant(small, wide, [&](auto v, auto img) {
         constexpr int V = decltype(v)::value, IMG = decltype(img)::value;
-        if (swap) k_tile_decode<true, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
-        else      k_tile_decode<false, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, f->tv, wd, cd, n, c->status, nvalid);
+        if (swap) k_tile_decode<true, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, tile_vars_of(f->tv, cd), wd, cd, n, c->status, nvalid);
+        else      k_tile_decode<false, V, IMG><<<tiles, TILE_TPB, 0, st>>>(f->dev, tile_vars_of(f->tv, cd), wd, cd, n, c->status, nvalid);
     });
     LAUNCHED("k_tile_decode");
     return perf_end(c, st, timed, 0);

@@ -65,7 +65,23 @@ struct TileVars {                       // the variable fields of the format, in
     int32_t nv;
     int32_t field[TILE_MAXV];
     int32_t width[TILE_MAXV];           // element width of each (kept here: one scalar load, no chain)
+    // Of the wave's columns, per launch (tile_vars_of): offs[] and capacity of variable field v under
+    // the index v itself.  cols.offs[tv.field[v]] is two look-ups into the kernel arguments, the
+    // second at an index that the first one loaded -- two dependent scalar loads in front of the
+    // load that is wanted (and, indexed per lane, two dependent round trips to memory).
+    uint64_t *offs[TILE_MAXV];
+    uint64_t  cap[TILE_MAXV];
 };
+
+__host__ inline TileVars tile_vars_of(const TileVars &fmt_vars, const ColsDev &cols)
+{
+    TileVars tv = fmt_vars;
+    for (int v = 0; v < TILE_MAXV; v++) {
+        tv.offs[v] = v < tv.nv ? cols.offs[tv.field[v]] : nullptr;
+        tv.cap[v] = v < tv.nv ? cols.cap[tv.field[v]] : 0;
+    }
+    return tv;
+}
 
 // MAXV = variable fields the tables hold: formats with up to 4 take the small form, which leaves
 // room for a fifth workgroup per CU (measured on a 1M-packet wave: +11 % throughput).
@@ -113,15 +129,18 @@ struct TileNothing { __device__ __forceinline__ void operator()() const {} };
 // has to wait for ALL loads where a conditional one may or may not have been issued.)
 template <bool SEGS, bool CAPS, int IMG, typename L, typename F = TileNothing>
 __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const WireDev &wire,
-                                               const ColsDev &cols, uint64_t p0, uint32_t np, uint64_t n,
-                                               F after_loads = F())
+                                               uint64_t p0, uint32_t np, uint64_t n, F after_loads = F())
 {
     const uint32_t t = threadIdx.x;
     if (t == 0) { m.staged = 1; m.packed = 1; m.too_small = 0; }
+    // (the same for every lane of every tile: scalar loads, issued here and not needed before the
+    // second barrier.  As a per-lane look-up -- lane v asking for cols.offs[tv.field[v]][n] -- this was
+    // three dependent round trips to memory that the last wavefront brought to the first barrier.)
     bool over = false;
-    if (CAPS && t >= TILE_TPB - TILE_MAXV && (int)(t - (TILE_TPB - TILE_MAXV)) < tv.nv) {
-        const int f = tv.field[t - (TILE_TPB - TILE_MAXV)];
-        over = cols.offs[f][n] > cols.cap[f];
+    if (CAPS) {
+#pragma unroll
+        for (int v = 0; v < L::NV; v++)
+            if (v < tv.nv) over = over || tv.offs[v][n] > tv.cap[v];
     }
     // every load of the round is issued before the first LDS store waits for one of them
     uint64_t s0 = 0, l0 = 0;
@@ -129,7 +148,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
     uint64_t sg[L::NV];
     if (SEGS) {
 #pragma unroll
-        for (int v = 0; v < L::NV; v++) sg[v] = (v < tv.nv && t <= np) ? cols.offs[tv.field[v]][p0 + t] : 0;
+        for (int v = 0; v < L::NV; v++) sg[v] = (v < tv.nv && t <= np) ? tv.offs[v][p0 + t] : 0;
     }
     if (t < np) {
         m.start[t] = s0;
@@ -156,7 +175,7 @@ __device__ __forceinline__ void tile_load_meta(L &m, const TileVars &tv, const W
             const uint64_t room = (e >= s && s <= wire.bytes && e - s <= wire.bytes - s) ? e - s : 0;
             for (int v = 0; v < tv.nv; v++) {
                 const uint64_t a = m.seg[v][t], b = m.seg[v][t + 1];
-                sane = sane && b >= a && (b - a) <= room && (b - a) * (uint64_t)tv.width[v] <= room && b <= cols.cap[tv.field[v]];
+                sane = sane && b >= a && (b - a) <= room && (b - a) * (uint64_t)tv.width[v] <= room && b <= tv.cap[v];
             }
             if (!sane) m.too_small = 1;
         }
@@ -589,7 +608,7 @@ __global__ __launch_bounds__(TILE_TPB) void k_tile_encode(FmtDev fmt, TileVars t
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     TILE_STAMP(0);
-    tile_load_meta<true, false, IMG>(m, tv, wire, cols, p0, np, n);
+    tile_load_meta<true, false, IMG>(m, tv, wire, p0, np, n);
     if (m.staged) tile_encode_body<true>(m, img, fmt, tv, wire, cols, p0, np);
     else          tile_encode_body<false>(m, img, fmt, tv, wire, cols, p0, np);
 }
@@ -607,7 +626,7 @@ __global__ __launch_bounds__(TILE_TPB) void k_tile_walk(FmtDev fmt, TileVars tv,
     const uint64_t p0 = (uint64_t)blockIdx.x * TILE_PKTS;
     const uint32_t np = (uint32_t)((n - p0) < TILE_PKTS ? (n - p0) : TILE_PKTS);
     const uint32_t t = threadIdx.x;
-    tile_load_meta<false, false, IMG>(m, tv, wire, cols, p0, np, n);
+    tile_load_meta<false, false, IMG>(m, tv, wire, p0, np, n);
     const bool staged = m.staged != 0;
     const uint64_t lo = m.start[0];
     const uint32_t mis = (uint32_t)((uintptr_t)(wire.base + lo) & 15u);
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(TILE_TPB) void k_tile_decode(FmtDev fmt, TileVars t
     // written, the status word says so
     // the image's loads go out before the boundaries are checked, and arrive while they are
     TileStage<IMG> early;
-    tile_load_meta<true, true, IMG>(m, tv, wire, cols, p0, np, n, [&]() { early.issue(wire, p0, np); });
+    tile_load_meta<true, true, IMG>(m, tv, wire, p0, np, n, [&]() { early.issue(wire, p0, np); });
     TILE_STAMP(1);
     const bool skip = m.too_small != 0;          // no payload moves (the scalar columns are still written)
     if (skip && t == 0) atomicOr(status, 1u);
