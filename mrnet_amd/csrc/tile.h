@@ -419,11 +419,54 @@ __device__ __forceinline__ void tile_drain_field(L &m, const uint8_t *img, int v
         }
 }
 
+// Decode of a field that is SHORT in this tile (a dozen bytes per packet: names, small vectors): one
+// wavefront, one lane per packet, instead of sixteen lanes per packet in all four.  Sixteen lanes
+// on a 13-byte string is fifteen lanes of predicated-off instructions, and every wavefront of the
+// workgroup issues them; here the other wavefronts go on to the next field meanwhile.  A lane moves
+// 128-bit pieces while they fit (a few iterations at most for the odd long packet), then the rest
+// as one masked 8 / 4 / 2 / 1-byte cascade out of a 16-byte LDS read (reading past the packet's
+// end stays inside the image, which keeps 32 spare bytes).
+#define TILE_SHORT_AVG 32u             // bytes per packet, averaged over the tile, up to which a field counts as short
+
+template <bool SWAP, int W, typename L>
+__device__ __forceinline__ void tile_drain_short(L &m, const uint8_t *img, int v, uint32_t pre, uint8_t *dense,
+                                                 uint32_t np, uint64_t lo, uint32_t mis)
+{
+    const uint32_t i = threadIdx.x & 63u;
+    if (i >= np) return;
+    const uint64_t s_lo = m.seg[v][i] * W;
+    const uint32_t len = (uint32_t)(m.seg[v][i + 1] * W - s_lo);
+    const uint8_t *src = img + (uint32_t)(m.start[i] + m.vpos[v][i] + pre - lo) + mis;
+    uint8_t *dst = dense + s_lo;
+    uint32_t o = 0;
+    for (; o + 16u <= len; o += 16u) {
+        const u32x4 x = ld16_u(src + o);
+        st16_any<false>(dst + o, SWAP ? swap_elems<W>(x) : x);
+    }
+    const uint32_t r = len - o;            // < 16, a multiple of W
+    if (r == 0) return;
+    u32x4 x = ld16_u(src + o);
+    if (SWAP) x = swap_elems<W>(x);
+    dst += o;
+    uint32_t a = x[0], b = x[1];
+    if (r & 8u) { st_u<uint64_t>(dst, (uint64_t)a | ((uint64_t)b << 32)); dst += 8; a = x[2]; b = x[3]; }
+    if (r & 4u) { st_u<uint32_t>(dst, a); dst += 4; a = b; }
+    if (W <= 2 && (r & 2u)) { st_u<uint16_t>(dst, (uint16_t)a); dst += 2; a >>= 16; }
+    if (W == 1 && (r & 1u)) st_u<uint8_t>(dst, (uint8_t)a);
+}
+
 template <bool STAGED, bool ENCODE, bool SWAP, int W, typename L>
 __device__ __forceinline__ void tile_copy_field(L &m, uint8_t *img, const WireDev &wire, int v, uint32_t pre,
                                                 uint8_t *dense, uint32_t np, uint64_t lo, uint32_t mis)
 {
     if (STAGED && !ENCODE) {        // (the staged encode is driven by tile_encode_body itself)
+        const uint32_t bytes = __builtin_amdgcn_readfirstlane((uint32_t)((m.seg[v][np] - m.seg[v][0]) * W));
+        if (bytes <= np * TILE_SHORT_AVG) {
+            // (wavefront v of the four: with several short fields they go side by side)
+            if (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == (v & (TILE_TPB / 64 - 1)))
+                tile_drain_short<SWAP, W>(m, img, v, pre, dense, np, lo, mis);
+            return;
+        }
         tile_drain_field<SWAP, W>(m, img, v, pre, dense, np, lo, mis);
         return;
     }
