@@ -11,7 +11,7 @@ for so in "$@"; do
   python3 - "$f" <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if r["Name"].split("(")[0].replace("void ","").startswith(("k_tile","k_size","k_scan","k_copy","k_walk")) and int(r["Calls"])>10:
+    if r["Name"].split("(")[0].replace("void ","").startswith(("k_tile","k_size","k_scan","k_copy","k_walk","k_count")) and int(r["Calls"])>10:
         print("   %-34s calls %4s avg %8.1f us" % (r["Name"].split("(")[0][:34], r["Calls"], float(r["AverageNs"])/1e3))
 PY
 done
