@@ -336,6 +336,19 @@ def small_wave_extras(codec):
         f_avg = codec.bind_filter(W.TFILTER_AVG, W.DataType.DOUBLE_T, p64, 12, p64 + 8, 12, n, 0, shape, res, rok)
         i_avg = codec.bind_filter(W.TFILTER_AVG, W.DataType.INT32_T, p64, 12, p64 + 8, 12, n, 0, shape, res, rok)
         out["%s_sum_f32_64k_us" % name] = round(time_call(f_sum, 50) * 1e6, 1)
+        if name == "flat":
+            # the flat float results are the reference's chain of additions; large waves take it a binade
+            # at a time with a scan.  What that buys depends on the data: a sum that grows (timings,
+            # counts) stays in a binade for long stretches, a zero-mean one hovers around powers of two
+            vpos = torch.rand(n, dtype=torch.float32, device=dev)
+            f_pos = codec.bind_filter(W.TFILTER_SUM, W.DataType.FLOAT_T, vpos.data_ptr(), 4, None, 0, n, 0, shape, res, rok)
+            f_pos_chain = codec.bind_filter(W.TFILTER_SUM, W.DataType.FLOAT_T, vpos.data_ptr(), 4, None, 0, n, 0,
+                                            W.SHAPE_FLAT_SERIAL, res, rok)
+            f_avg_chain = codec.bind_filter(W.TFILTER_AVG, W.DataType.DOUBLE_T, p64, 12, p64 + 8, 12, n, 0,
+                                            W.SHAPE_FLAT_SERIAL, res, rok)
+            out["flat_sum_f32_64k_positive_us"] = round(time_call(f_pos, 50) * 1e6, 1)
+            out["flat_sum_f32_64k_positive_plain_chain_us"] = round(time_call(f_pos_chain, 50) * 1e6, 1)
+            out["flat_avg_f64_64k_plain_chain_us"] = round(time_call(f_avg_chain, 50) * 1e6, 1)
         out["%s_avg_f64_64k_us" % name] = round(time_call(f_avg, 50) * 1e6, 1)
         out["%s_avg_i32_64k_us" % name] = round(time_call(i_avg, 50) * 1e6, 1)
     # config 5 shape: '%lf %d', fused Min / Max / Avg on the wire (one GPU's 131,072-packet shard)

@@ -73,9 +73,16 @@ enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 
  * Shape of the reduction a filter call applies to a wave.
  *   MRPDR_SHAPE_FLAT  one left fold over all n packets, i.e. exactly one call of the
  *                     reference's tfilter_* on the whole wave (exact for every type and
- *                     operator at any n; serial where the order matters -- float types,
- *                     every AVG -- while integer SUM / MIN / MAX / OR / AND, whose bits do
- *                     not depend on the order, are computed level by level)
+ *                     operator at any n).  How the bits are reached is the library's
+ *                     business: integer SUM / MIN / MAX / OR / AND, integer AVG and float
+ *                     MIN / MAX level by level; float and double SUM / AVG -- where every
+ *                     addition rounds -- by the chain of additions itself, which large
+ *                     waves take a binade at a time with a scan over the sum's integer
+ *                     grid instead of one dependent addition per packet
+ *   MRPDR_SHAPE_FLAT_SERIAL  the same result with float / double SUM and AVG computed by
+ *                     the plain chain only, one addition after the other as the reference's
+ *                     loop is written (for cross-checks; identical bits, slower on large
+ *                     waves); every other operator and type as MRPDR_SHAPE_FLAT
  *   MRPDR_SHAPE_TREE  the same fold applied level by level over a fixed tree, the way
  *                     an MRNet tree applies it at every internal node:
  *                     fan-in 4, then 2,2,2,2,2,2, then 4, then all remaining nodes
@@ -83,7 +90,7 @@ enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 
  *                     skipped).  Integer SUM and NaN-free MIN/MAX give the same bits
  *                     as FLAT; float SUM and every AVG depend on the shape.
  */
-enum mrpdr_shape { MRPDR_SHAPE_FLAT = 0, MRPDR_SHAPE_TREE = 1 };
+enum mrpdr_shape { MRPDR_SHAPE_FLAT = 0, MRPDR_SHAPE_TREE = 1, MRPDR_SHAPE_FLAT_SERIAL = 2 };
 
 /* fan-ins of MRPDR_SHAPE_TREE, 0 = all remaining nodes */
 #define MRPDR_TREE_LEVELS 9

@@ -12,6 +12,7 @@
 #include "rows.h"
 #include "copy.h"
 #include "filter.h"
+#include "flatscan.h"
 #include "header.h"
 #include "message.h"
 #include "strarr.h"
@@ -1202,11 +1203,21 @@ static int32_t run_tree(Partial *partials, const FilterIn &in, uint8_t *result, 
 // is computed level by level with the same bits: integer SUM / MIN / MAX / OR / AND as they are,
 // integer AVG as sums with one division at the top, float MIN / MAX with the NaN rule carried
 // through the levels.
+// Below this many packets the plain chain is a few microseconds and the scan's rounds do not pay.
+#define FLAT_SCAN_MIN 2048
+
 template <int OP, typename T>
-static int32_t run_flat(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
+static int32_t run_flat(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st,
+                        bool serial = false)
 {
     constexpr bool fp = std::is_floating_point<T>::value;
     if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
+        if (!serial && in.n >= FLAT_SCAN_MIN) {
+            // the same chain, taken a binade at a time by a scan (flatscan.h): same bits
+            k_filter_flat_scan<OP, T><<<1, SCAN_TPB, 0, st>>>(in, result, result_ok);
+            LAUNCHED("k_filter_flat_scan");
+            return 1;
+        }
         k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok);
         LAUNCHED("k_filter_flat");
         return 1;
@@ -1226,6 +1237,7 @@ static int32_t run_filter(Partial *partials, int32_t shape, const FilterIn &in, 
                           int32_t *result_ok, hipStream_t st)
 {
     if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(partials, in, result, result_ok, st);
+    if (shape == MRPDR_SHAPE_FLAT_SERIAL) return run_flat<OP, T>(partials, in, result, result_ok, st, true);
     return run_tree<OP, T>(partials, in, result, result_ok, st);
 }
 
@@ -1258,7 +1270,8 @@ static int32_t filter_dispatch(Partial *partials, int32_t op, int32_t type, int3
     if (!result) return fail("mrpdr_wave_filter: NULL result");
     if (n && !values) return fail("mrpdr_wave_filter: NULL values");
     if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
-    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("mrpdr_wave_filter: unknown shape %d", shape);
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE && shape != MRPDR_SHAPE_FLAT_SERIAL)
+        return fail("mrpdr_wave_filter: unknown shape %d", shape);
     if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
         return fail("mrpdr_wave_filter: bitwise operators need an integer type");
     FilterIn in = { (const uint8_t *)values, value_stride, (const uint8_t *)counts, count_stride, n, swap, orders };

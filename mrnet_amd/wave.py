@@ -62,7 +62,7 @@ SCALAR, ARRAY, STRING, STRING_ARRAY = 0, 1, 2, 3
 TFILTER_SUM, TFILTER_MIN, TFILTER_MAX, TFILTER_AVG = 0, 1, 2, 3      # operator codes of the C ABI
 TFILTER_ARRAY_CONCAT = 6          # tfilter_PerfData's concatenating aggregation (host-side code only)
 FILTER_OR, FILTER_AND = 4, 5      # bitwise (not built-in TFILTER_*: the BitsetOr / IntegerPercentiles examples)
-SHAPE_FLAT, SHAPE_TREE = 0, 1
+SHAPE_FLAT, SHAPE_TREE, SHAPE_FLAT_SERIAL = 0, 1, 2
 TREE_FANINS = (4, 2, 2, 2, 2, 2, 2, 4, 0)
 
 USER_STRM_BASE_ID = (1 << 30) + 10      # src/Stream.C:31-42
