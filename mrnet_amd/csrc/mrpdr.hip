@@ -1385,7 +1385,8 @@ extern "C" int32_t mrpdr_wave_decode_filter(mrpdr_ctx *c, const mrpdr_fmt *f, co
     if (sender_bo != MRPDR_LITTLEENDIAN && sender_bo != MRPDR_BIGENDIAN) return fail("%s: bad byte order %d", who, sender_bo);
     if (!f->fixed || f->dev.nf < 1) return fail("%s: needs a format of scalars only, the filtered value first", who);
     if (op < MRPDR_SUM || op > MRPDR_AND) return fail("%s: unknown operator %d", who, op);
-    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE) return fail("%s: unknown shape %d", who, shape);
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE && shape != MRPDR_SHAPE_FLAT_SERIAL)
+        return fail("%s: unknown shape %d", who, shape);
     if (op == MRPDR_AVG && (f->dev.nf < 2 || f->dev.f[1].type != MRPDR_INT32_T))
         return fail("%s: AVG needs the int32 count as second field", who);
     if (!result) return fail("%s: NULL result", who);
