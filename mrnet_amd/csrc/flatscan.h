@@ -326,9 +326,12 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
             // Book-keeping in packets: a round costs about what the plain chain needs for SCAN_PAYS
             // packets.  credit is what the rounds so far have saved (kept within bounds, so that old
             // history fades), miss counts rounds in a row that did not pay.
-            miss = first >= SCAN_PAYS ? 0u : miss + 1u;
-            credit += (int32_t)first - (int32_t)SCAN_PAYS;
-            credit = credit < -4 * (int32_t)SCAN_PAYS ? -4 * (int32_t)SCAN_PAYS : credit > 8 * (int32_t)SCAN_PAYS ? 8 * (int32_t)SCAN_PAYS : credit;
+            // (a round that the window's end cut short and that took all it was given says nothing)
+            if (first < len || len == SCAN_ROUND) {
+                miss = first >= SCAN_PAYS ? 0u : miss + 1u;
+                credit += (int32_t)first - (int32_t)SCAN_PAYS;
+                credit = credit < -4 * (int32_t)SCAN_PAYS ? -4 * (int32_t)SCAN_PAYS : credit > 8 * (int32_t)SCAN_PAYS ? 8 * (int32_t)SCAN_PAYS : credit;
+            }
             if (first == len) continue;
             // A packet that takes the sum out of its binade: it is added the plain way.  One round
             // that has not paid is no verdict (behind the packet the sum is at the start of a new
