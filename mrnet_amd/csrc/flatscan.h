@@ -13,13 +13,15 @@
 //                    S + I + (S + I is odd ? 1 : 0)   if F = 1/2  (ties go to the even neighbour).
 // So a packet is a map on S that depends on S only through its parity: two integers (the step for
 // an even S, the step for an odd S).  Such maps compose associatively -- (a then b)[p] =
-// a[p] + b[(p + a[p]) & 1] -- and a workgroup scans 2,048 of them in about a microsecond.  Every
+// a[p] + b[(p + a[p]) & 1] -- and a workgroup of 1,024 lanes scans 4,096 of them in about three
+// microseconds, where the chain of additions needs fifteen.  Every
 // lane then checks, for its own packets, that the exact sum really stayed inside the binade (an
 // integer range test on S + I, conservative at both ends); the scan's results are taken up to the
 // first packet where it did not, that packet is added the ordinary way (a hardware add, which moves
 // the sum to its new binade), and the next round starts from there.  Where rounds keep ending early
-// (sums hovering around a power of two, cancellations, zeros, infinities, NaNs) growing stretches
-// are folded the plain way, so the worst case stays near the plain chain.
+// (sums hovering around a power of two, cancellations, zeros, infinities, NaNs) stretches of the
+// wave are folded the plain way, so the worst case stays near the plain chain (measured: at most
+// 13 % over it; 2.2 to 2.9 times faster where the sum grows).
 //
 // The bits are those of the serial fold for every input: the tests compare both kernels and the
 // CPU oracle on ordinary, tie-heavy, cancelling, huge-range, subnormal and non-finite data.
