@@ -297,7 +297,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
             for (int k = 0; k < SCAN_EPL; k++) {
                 const bool fine = !st[k].cross && grid_inside<T>(p + st[k].floor_i);
                 if (!fine && bad == SCAN_EPL) { bad = (uint32_t)k; p_bad = p; }
-                p += st[k].step[p & 1];
+                p += (p & 1) ? st[k].step[1] : st[k].step[0];
             }
             uint32_t first = bad < SCAN_EPL ? t * SCAN_EPL + bad : SCAN_ROUND;
 #pragma unroll

@@ -13,6 +13,7 @@
 #include "copy.h"
 #include "filter.h"
 #include "flatscan.h"
+#include "flatwide.h"
 #include "header.h"
 #include "message.h"
 #include "strarr.h"
@@ -1180,20 +1181,31 @@ extern "C" int32_t mrpdr_message_write_frame(mrpdr_ctx *c, const mrpdr_fmt *f, u
 // ---------------------------------------------------------------------------
 // filters
 // ---------------------------------------------------------------------------
+// Device memory a filter call may use between its launches: the tree nodes, and (ctx callers only)
+// room for the chunk summaries of the device-wide float fold (flatwide.h).
+struct FilterWs { Partial *partials; void *wide; uint64_t wide_bytes; };
+
+static FilterWs ctx_filter_ws(const mrpdr_ctx *c)
+{
+    // (the string-array scratch doubles as the summaries' room: a filter and a decode of one ctx are
+    // calls on one stream, one after the other)
+    return FilterWs{ c->partials, c->pkt_bytes, (c->max_packets + 1) * sizeof(uint64_t) };
+}
+
 template <int OP, typename T>
-static int32_t run_tree(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
+static int32_t run_tree(const FilterWs &fw, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st)
 {
     const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
     if (tiles == 1) {           // one tile: its workgroup takes the last level too
-        k_filter_tree_tile<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, partials, result, result_ok);
+        k_filter_tree_tile<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, fw.partials, result, result_ok);
         LAUNCHED("k_filter_tree_tile");
         return 1;
     }
     if (tiles) {
-        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, partials, nullptr, nullptr);
+        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, fw.partials, nullptr, nullptr);
         LAUNCHED("k_filter_tree_tile");
     }
-    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(partials, tiles, result, result_ok);
+    k_filter_tree_top<OP, T><<<1, MRPDR_TPB, 0, st>>>(fw.partials, tiles, result, result_ok);
     LAUNCHED("k_filter_tree_top");
     return 1;
 }
@@ -1205,13 +1217,28 @@ static int32_t run_tree(Partial *partials, const FilterIn &in, uint8_t *result, 
 // through the levels.
 // Below this many packets the plain chain is a few microseconds and the scan's rounds do not pay.
 #define FLAT_SCAN_MIN 2048
+// From here on three launches over the whole device beat the one workgroup.
+#define FLAT_WIDE_MIN 16384
 
 template <int OP, typename T>
-static int32_t run_flat(Partial *partials, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st,
+static int32_t run_flat(const FilterWs &fw, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st,
                         bool serial = false)
 {
     constexpr bool fp = std::is_floating_point<T>::value;
     if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
+        if (!serial && in.n >= FLAT_WIDE_MIN && fw.wide) {
+            // large waves: the per-packet work on the whole device, one workgroup walks the chunks
+            const uint64_t nc = (in.n + WIDE_CHUNK - 1) / WIDE_CHUNK;
+            if (WideWs<T>::bytes(nc) <= fw.wide_bytes) {
+                k_wide_sums<OP, T><<<(uint32_t)nc, WIDE_TPB, 0, st>>>(in, fw.wide, nc);
+                LAUNCHED("k_wide_sums");
+                k_wide_maps<OP, T><<<(uint32_t)nc, WIDE_TPB, 0, st>>>(in, fw.wide, nc);
+                LAUNCHED("k_wide_maps");
+                k_wide_walk<OP, T><<<1, WIDE_TPB, 0, st>>>(in, fw.wide, nc, result, result_ok);
+                LAUNCHED("k_wide_walk");
+                return 1;
+            }
+        }
         if (!serial && in.n >= FLAT_SCAN_MIN) {
             // the same chain, taken a binade at a time by a scan (flatscan.h): same bits
             k_filter_flat_scan<OP, T><<<1, SCAN_TPB, 0, st>>>(in, result, result_ok);
@@ -1222,46 +1249,46 @@ static int32_t run_flat(Partial *partials, const FilterIn &in, uint8_t *result, 
         LAUNCHED("k_filter_flat");
         return 1;
     } else if constexpr (fp && OP == MRPDR_MIN) {
-        return run_tree<OP_MINR, T>(partials, in, result, result_ok, st);
+        return run_tree<OP_MINR, T>(fw, in, result, result_ok, st);
     } else if constexpr (fp && OP == MRPDR_MAX) {
-        return run_tree<OP_MAXR, T>(partials, in, result, result_ok, st);
+        return run_tree<OP_MAXR, T>(fw, in, result, result_ok, st);
     } else if constexpr (!fp && OP == MRPDR_AVG) {
-        return run_tree<OP_AVGSUM, T>(partials, in, result, result_ok, st);
+        return run_tree<OP_AVGSUM, T>(fw, in, result, result_ok, st);
     } else {
-        return run_tree<OP, T>(partials, in, result, result_ok, st);
+        return run_tree<OP, T>(fw, in, result, result_ok, st);
     }
 }
 
 template <int OP, typename T>
-static int32_t run_filter(Partial *partials, int32_t shape, const FilterIn &in, uint8_t *result,
+static int32_t run_filter(const FilterWs &fw, int32_t shape, const FilterIn &in, uint8_t *result,
                           int32_t *result_ok, hipStream_t st)
 {
-    if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(partials, in, result, result_ok, st);
-    if (shape == MRPDR_SHAPE_FLAT_SERIAL) return run_flat<OP, T>(partials, in, result, result_ok, st, true);
-    return run_tree<OP, T>(partials, in, result, result_ok, st);
+    if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(fw, in, result, result_ok, st);
+    if (shape == MRPDR_SHAPE_FLAT_SERIAL) return run_flat<OP, T>(fw, in, result, result_ok, st, true);
+    return run_tree<OP, T>(fw, in, result, result_ok, st);
 }
 
 template <typename T>
-static int32_t run_filter_op(Partial *partials, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
+static int32_t run_filter_op(const FilterWs &fw, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
                              int32_t *result_ok, hipStream_t st)
 {
     switch (op) {
-    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(partials, shape, in, result, result_ok, st);
-    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(partials, shape, in, result, result_ok, st);
-    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(partials, shape, in, result, result_ok, st);
-    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(partials, shape, in, result, result_ok, st);
+    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(fw, shape, in, result, result_ok, st);
+    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(fw, shape, in, result, result_ok, st);
+    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(fw, shape, in, result, result_ok, st);
+    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(fw, shape, in, result, result_ok, st);
     case MRPDR_OR:
-        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_OR, T>(partials, shape, in, result, result_ok, st);
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_OR, T>(fw, shape, in, result, result_ok, st);
         break;
     case MRPDR_AND:
-        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_AND, T>(partials, shape, in, result, result_ok, st);
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_AND, T>(fw, shape, in, result, result_ok, st);
         break;
     }
     return fail("mrpdr_wave_filter: unknown operator %d", op);
 }
 
 // Argument checks and type dispatch shared by the ctx entry points and the one that allocates nothing.
-static int32_t filter_dispatch(Partial *partials, int32_t op, int32_t type, int32_t shape,
+static int32_t filter_dispatch(const FilterWs &fw, int32_t op, int32_t type, int32_t shape,
                                const void *values, uint64_t value_stride,
                                const void *counts, uint64_t count_stride,
                                uint64_t n, int32_t swap, const uint8_t *orders,
@@ -1278,16 +1305,16 @@ static int32_t filter_dispatch(Partial *partials, int32_t op, int32_t type, int3
     uint8_t *res = (uint8_t *)result;
     hipStream_t st = (hipStream_t)stream;
     switch (type) {
-    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_INT16_T:  return run_filter_op<int16_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_INT32_T:  return run_filter_op<int32_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_INT64_T:  return run_filter_op<int64_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_FLOAT_T:  return run_filter_op<float>(partials, op, shape, in, res, result_ok, st);
-    case MRPDR_DOUBLE_T: return run_filter_op<double>(partials, op, shape, in, res, result_ok, st);
+    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_INT16_T:  return run_filter_op<int16_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_INT32_T:  return run_filter_op<int32_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_INT64_T:  return run_filter_op<int64_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_FLOAT_T:  return run_filter_op<float>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_DOUBLE_T: return run_filter_op<double>(fw, op, shape, in, res, result_ok, st);
     }
     // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
     return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
@@ -1301,7 +1328,7 @@ static int32_t wave_filter(mrpdr_ctx *c, int32_t op, int32_t type, int32_t shape
 {
     if (!ctx_ready("mrpdr_wave_filter", c)) return 0;
     if (n > c->max_packets) return fail("mrpdr_wave_filter: n exceeds the ctx limit");
-    return filter_dispatch(c->partials, op, type, shape, values, value_stride, counts, count_stride, n, swap, orders,
+    return filter_dispatch(ctx_filter_ws(c), op, type, shape, values, value_stride, counts, count_stride, n, swap, orders,
                            result, result_ok, stream);
 }
 
@@ -1403,7 +1430,7 @@ extern "C" int32_t mrpdr_wave_decode_filter(mrpdr_ctx *c, const mrpdr_fmt *f, co
     if (n == 0 || top < 0 || !rows_path_ok(f, wd) || wd.stride > FUSED_MAX_STRIDE) {
         // what the one pass cannot do: decode, then the filter over the decoded columns
         if (!decode_begin(who, c, f, wire, n, sender_bo, nullptr, cols, ok, nullptr, stream)) return 0;
-        return filter_dispatch(c->partials, op, type, shape, n ? cols[0].values : nullptr, f->dev.f[0].width,
+        return filter_dispatch(ctx_filter_ws(c), op, type, shape, n ? cols[0].values : nullptr, f->dev.f[0].width,
                                (n && op == MRPDR_AVG) ? cols[1].values : nullptr, 4, n, 0, nullptr, result, result_ok, stream);
     }
     uint8_t *res = (uint8_t *)result;
@@ -1465,7 +1492,7 @@ extern "C" int32_t mrpdr_wave_filter_noalloc(int32_t op, int32_t type, int32_t s
     void *ptr = nullptr;
     if (!scratch_of_current_device("mrpdr_wave_filter_noalloc", &ptr)) return 0;
     // nothing in the array has to start from zero: the first launch writes every node the second reads
-    return filter_dispatch((Partial *)ptr, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
+    return filter_dispatch(FilterWs{ (Partial *)ptr, nullptr, 0 }, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
                            result, result_ok, stream);
 }
 
