@@ -1492,7 +1492,9 @@ extern "C" int32_t mrpdr_wave_filter_noalloc(int32_t op, int32_t type, int32_t s
     void *ptr = nullptr;
     if (!scratch_of_current_device("mrpdr_wave_filter_noalloc", &ptr)) return 0;
     // nothing in the array has to start from zero: the first launch writes every node the second reads
-    return filter_dispatch(FilterWs{ (Partial *)ptr, nullptr, 0 }, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
+    // (a call uses the array either for tree nodes or for the chunk summaries of a large float fold,
+    // never for both; waves whose summaries do not fit take the one-workgroup scan)
+    return filter_dispatch(FilterWs{ (Partial *)ptr, ptr, sizeof scratch }, op, type, shape, values, value_stride, counts, count_stride, n, swap, nullptr,
                            result, result_ok, stream);
 }
 

@@ -21,6 +21,7 @@ CASES = [  # (operator, DataType, numpy dtype, shape)
     (W.TFILTER_MAX, W.DataType.INT16_T, np.int16, W.SHAPE_TREE),
     (W.TFILTER_AVG, W.DataType.INT64_T, np.int64, W.SHAPE_FLAT),
     (W.TFILTER_AVG, W.DataType.DOUBLE_T, np.float64, W.SHAPE_TREE),
+    (W.TFILTER_AVG, W.DataType.DOUBLE_T, np.float64, W.SHAPE_FLAT),      # (300,001 packets: chunk summaries in the built-in array)
     (W.FILTER_OR, W.DataType.UINT64_T, np.uint64, W.SHAPE_TREE),
 ]
 
