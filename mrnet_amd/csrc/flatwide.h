@@ -24,9 +24,11 @@
 
 #include "flatscan.h"
 
-#define WIDE_CHUNK 1024u
+#ifndef WIDE_TPB
 #define WIDE_TPB 256
+#endif
 #define WIDE_EPL 4
+#define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
 static_assert(WIDE_TPB * WIDE_EPL == WIDE_CHUNK, "a lane owns consecutive packets of its chunk");
