@@ -31,18 +31,36 @@
 #define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
-static_assert(WIDE_TPB * WIDE_EPL == WIDE_CHUNK, "a lane owns consecutive packets of its chunk");
 
-template <typename S> struct WideSum { S step[2], lo[2], hi[2]; };
-struct WideHead { int32_t e0; uint32_t bad; };      // candidates e0 .. e0 + WIDE_K - 1; bit k: candidate k does not apply
+#define WIDE_SUBS (WIDE_TPB / 64)        // a wavefront's packets (256) are a sub-chunk with summaries of its own
+static_assert(WIDE_TPB * WIDE_EPL == WIDE_CHUNK && 4 + WIDE_K * WIDE_SUBS <= 31, "head.bad holds a bit per candidate and sub-chunk");
+
+// What a run of packets does to a sum of parity p in front of it is of[p]: the least and the greatest
+// exact partial sum inside the run and the run's total step, all relative to S.  (One side is what the
+// walk reads per chunk: 16 or 32 bytes, one or two LDS reads.)
+// `e` is the exponent the side is for (WIDE_NO_E: for none -- a packet of the run is out of that
+// exponent's reach, or the exponent is not a normal number's): the walk reads all three candidates'
+// sides at once and takes the one whose e is the sum's, without looking anything else up.
+template <typename S> struct WideSide { S lo, hi, step, e; };
+#define WIDE_NO_E(S) ((S)1 << 30)
+template <typename S> struct __align__(16) WideSum { WideSide<S> of[2]; };
+// Candidates e0 .. e0 + WIDE_K - 1.  bad, bit k: candidate k does not apply to the chunk as a whole;
+// bit 4 + k * WIDE_SUBS + w: nor to its sub-chunk w; WIDE_HINT: the walk will probably have to open the chunk.
+struct WideHead { int32_t e0; uint32_t bad; };
+#define WIDE_HINT 0x80000000u
+#define WIDE_CHUNK_BITS ((1u << WIDE_K) - 1u)
+#define WIDE_ALL_BAD ((1u << (4 + WIDE_K * WIDE_SUBS)) - 1u)
+__host__ __device__ constexpr uint32_t wide_bad_sub(int cand, uint32_t w) { return 1u << (4 + cand * WIDE_SUBS + (int)w); }
+__host__ __device__ constexpr uint32_t wide_bad_all_of(int cand) { return (1u << cand) | (((1u << WIDE_SUBS) - 1u) << (4 + cand * WIDE_SUBS)); }
 
 // Workspace of a wave of n packets (16-byte aligned): chunk sums, chunk counts, heads, summaries.
 template <typename T> struct WideWs {
     typedef typename Grid<T>::S S;
-    double *sums; int32_t *cnts; WideHead *heads; WideSum<S> *maps;
+    double *sums; int32_t *cnts; WideHead *heads; WideSum<S> *maps, *subs;
     __host__ __device__ static uint64_t bytes(uint64_t nc)
     {
-        return up(nc * sizeof(double)) + up(nc * sizeof(int32_t)) + up(nc * sizeof(WideHead)) + up(nc * WIDE_K * sizeof(WideSum<S>));
+        return up(nc * sizeof(double)) + up(nc * sizeof(int32_t)) + up(nc * sizeof(WideHead)) + up(nc * WIDE_K * sizeof(WideSum<S>)) +
+               up(nc * WIDE_K * WIDE_SUBS * sizeof(WideSum<S>));
     }
     __host__ __device__ static uint64_t up(uint64_t b) { return (b + 15) & ~(uint64_t)15; }
     __host__ __device__ WideWs(void *base, uint64_t nc)
@@ -51,7 +69,8 @@ template <typename T> struct WideWs {
         sums = (double *)p; p += up(nc * sizeof(double));
         cnts = (int32_t *)p; p += up(nc * sizeof(int32_t));
         heads = (WideHead *)p; p += up(nc * sizeof(WideHead));
-        maps = (WideSum<S> *)p;
+        maps = (WideSum<S> *)p; p += up(nc * WIDE_K * sizeof(WideSum<S>));
+        subs = (WideSum<S> *)p;
     }
 };
 
@@ -106,121 +125,294 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_sums(FilterIn in, void *ws_ba
 }
 
 // ---- pass 2: what every chunk does to a sum of its guessed exponent and of the two next to it ------
+// lo / hi never leave +-2^(MANT+3): anything at or beyond 2^(MANT+2) in size fails the walk's test for
+// every S, and kept small it cannot wrap when S or a step in front is added to it.
+template <typename T> __device__ __forceinline__ typename Grid<T>::S wide_clamp(typename Grid<T>::S v)
+{
+    typedef typename Grid<T>::S S;
+    const S c = (S)1 << (Grid<T>::MANT + 3);
+    return v > c ? c : (v < -c ? -c : v);
+}
+
+// What two runs of packets do one after the other (b behind a), from what each does on its own.
+template <typename T> __device__ __forceinline__ WideSum<typename Grid<T>::S> wide_then(const WideSum<typename Grid<T>::S> &a, const WideSum<typename Grid<T>::S> &b)
+{
+    typedef typename Grid<T>::S S;
+    WideSum<S> c;
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const S st = a.of[p].step;
+        const bool odd = ((p + (int)(st & 1)) & 1) != 0;        // the parity of S + st
+        const S bl = st + (odd ? b.of[1].lo : b.of[0].lo), bh = st + (odd ? b.of[1].hi : b.of[0].hi);
+        c.of[p].lo = wide_clamp<T>(a.of[p].lo < bl ? a.of[p].lo : bl);
+        c.of[p].hi = wide_clamp<T>(a.of[p].hi > bh ? a.of[p].hi : bh);
+        c.of[p].step = st + (odd ? b.of[1].step : b.of[0].step);
+        c.of[p].e = a.of[p].e == b.of[p].e ? a.of[p].e : WIDE_NO_E(S);
+    }
+    return c;
+}
+
+// every exact partial sum S + lo .. S + hi inside the binade (the same conservative ends as
+// grid_inside, drawn in by `margin`), all on one side of zero
+template <typename T> __device__ __forceinline__ bool wide_inside(typename Grid<T>::S l, typename Grid<T>::S h, typename Grid<T>::S margin)
+{
+    typedef typename Grid<T>::S S;
+    const S LO = (S)1 << Grid<T>::MANT, HI = ((S)1 << (Grid<T>::MANT + 1)) - 2;
+    return (l >= LO + margin && h <= HI - margin) || (h <= -LO - 1 - margin && l >= -HI + margin);
+}
+
 template <int OP, typename T>
 __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_base, uint64_t nc)
 {
     typedef Grid<T> G;
     typedef typename G::S S;
     __shared__ double s_part[WIDE_TPB / 64];
-    __shared__ GridMap<S> s_wave[WIDE_TPB / 64];
-    __shared__ S s_lo[2][WIDE_TPB / 64], s_hi[2][WIDE_TPB / 64];
+    __shared__ WideSum<S> s_sub[WIDE_K * WIDE_SUBS];
+    __shared__ uint32_t s_bad;
     WideWs<T> ws(ws_base, nc);
     const uint64_t c = blockIdx.x;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t == 0) s_bad = 0;
+    const bool whole = (c + 1) * WIDE_CHUNK <= in.n;            // (the last, partial chunk is folded plainly)
+    // the chunk's packets first: their loads are in flight while the sums in front are added up
+    T x[WIDE_EPL];
+    int32_t unused = 0;
+#pragma unroll
+    for (int k = 0; k < WIDE_EPL; k++) x[k] = whole ? wide_value<OP, T>(in, c * WIDE_CHUNK + t * WIDE_EPL + (uint32_t)k, &unused) : (T)0;
     // the sum in front of the chunk, roughly
     double a = 0;
     for (uint64_t j = t; j < c; j += WIDE_TPB) a += ws.sums[j];
-    a = wide_block_sum(a, s_part);
+    a = wide_block_sum(a, s_part);                              // (its barriers are behind s_bad = 0)
     WideHead head;
-    head.e0 = 0; head.bad = (1u << WIDE_K) - 1u;
+    head.e0 = 0; head.bad = WIDE_ALL_BAD;
     uint64_t abits;
     __builtin_memcpy(&abits, &a, 8);
     const int aef = (int)((abits >> 52) & 0x7ff);
-    const bool whole = (c + 1) * WIDE_CHUNK <= in.n;            // (the last, partial chunk is folded plainly)
     if (whole && aef != 0 && aef != 0x7ff) {
         head.e0 = aef - 1023 - 1;
         head.bad = 0;
         for (int k = 0; k < WIDE_K; k++) {
             const int e = head.e0 + k;
-            if (e < 1 - G::BIAS || e > G::EMASK - 1 - G::BIAS) head.bad |= 1u << k;     // not a normal number of T
+            if (e < 1 - G::BIAS || e > G::EMASK - 1 - G::BIAS) head.bad |= wide_bad_all_of(k);     // not a normal number of T
         }
     }
-    if (head.bad != (1u << WIDE_K) - 1u) {
-        T x[WIDE_EPL];
-        int32_t unused = 0;
+    if ((head.bad & WIDE_CHUNK_BITS) != WIDE_CHUNK_BITS) {
+        // The candidates side by side, not one after the other: three independent chains of shuffles.
+        // (A candidate already marked bad is computed as well and not looked at.)  Every wavefront
+        // sums up its own 256 packets, relative to the first of them.
+        GridStep<T> st[WIDE_K][WIDE_EPL];
+        GridMap<S> inc[WIDE_K], exc[WIDE_K];
+        uint32_t cross = 0;
 #pragma unroll
-        for (int k = 0; k < WIDE_EPL; k++) x[k] = wide_value<OP, T>(in, c * WIDE_CHUNK + t * WIDE_EPL + (uint32_t)k, &unused);
         for (int cand = 0; cand < WIDE_K; cand++) {
-            if ((head.bad >> cand) & 1u) continue;              // (uniform)
-            const int e = head.e0 + cand;
-            GridStep<T> st[WIDE_EPL];
             GridMap<S> f;
             f.a0 = f.a1 = 0;
-            bool cross = false;
 #pragma unroll
             for (int k = 0; k < WIDE_EPL; k++) {
-                st[k] = grid_step<T>(x[k], e);
-                cross = cross || st[k].cross;
+                st[cand][k] = grid_step<T>(x[k], head.e0 + cand);
+                cross |= st[cand][k].cross ? 1u << cand : 0u;
                 GridMap<S> g;
-                g.a0 = st[k].step[0]; g.a1 = st[k].step[1];
+                g.a0 = st[cand][k].step[0]; g.a1 = st[cand][k].step[1];
                 f = grid_then(f, g);
             }
-            GridMap<S> inc = f;
+            inc[cand] = f;
+        }
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const GridMap<S> o = grid_shfl_up(inc, d);
-                if ((int)lane >= d) inc = grid_then(o, inc);
-            }
-            GridMap<S> exc = grid_shfl_up(inc, 1);
-            if (lane == 0) exc.a0 = exc.a1 = 0;
-            __syncthreads();                                    // (s_wave, s_lo, s_hi of the candidate before)
-            if (lane == 63) s_wave[wave] = inc;
-            const bool any_cross = __syncthreads_or(cross) != 0;
-            GridMap<S> pre, total;
-            pre.a0 = pre.a1 = total.a0 = total.a1 = 0;
-            for (uint32_t w = 0; w < WIDE_TPB / 64; w++) {
-                if (w == wave) pre = total;
-                total = grid_then(total, s_wave[w]);
-            }
-            exc = grid_then(pre, exc);
-            // the exact partial sums of this lane's packets, relative to S, for both parities of S
-            S lo[2], hi[2];
+        for (int d = 1; d < 64; d <<= 1) {
 #pragma unroll
-            for (int p = 0; p < 2; p++) {
-                S q = p ? exc.a1 : exc.a0;
-                lo[p] = hi[p] = q + st[0].floor_i;
-#pragma unroll
-                for (int k = 0; k < WIDE_EPL; k++) {
-                    const S tf = q + st[k].floor_i;
-                    lo[p] = tf < lo[p] ? tf : lo[p];
-                    hi[p] = tf > hi[p] ? tf : hi[p];
-                    q += ((p + (int)(q & 1)) & 1) ? st[k].step[1] : st[k].step[0];      // (a select: an index would send st[] to scratch memory)
-                }
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) {
-                    const S ol = grid_lane(lo[p], (int)(lane ^ (uint32_t)d)), oh = grid_lane(hi[p], (int)(lane ^ (uint32_t)d));
-                    lo[p] = ol < lo[p] ? ol : lo[p];
-                    hi[p] = oh > hi[p] ? oh : hi[p];
-                }
-                if (lane == 0) { s_lo[p][wave] = lo[p]; s_hi[p][wave] = hi[p]; }
-            }
-            __syncthreads();
-            if (t == 0) {
-                if (any_cross) head.bad |= 1u << cand;
-                WideSum<S> out;
-                for (int p = 0; p < 2; p++) {
-                    S l = s_lo[p][0], h = s_hi[p][0];
-                    for (int w = 1; w < WIDE_TPB / 64; w++) { l = s_lo[p][w] < l ? s_lo[p][w] : l; h = s_hi[p][w] > h ? s_hi[p][w] : h; }
-                    out.lo[p] = l; out.hi[p] = h;
-                    out.step[p] = p ? total.a1 : total.a0;
-                }
-                ws.maps[c * WIDE_K + cand] = out;
+            for (int cand = 0; cand < WIDE_K; cand++) {
+                const GridMap<S> o = grid_shfl_up(inc[cand], d);
+                if ((int)lane >= d) inc[cand] = grid_then(o, inc[cand]);
             }
         }
+        // the exact partial sums of this lane's packets, relative to S, for both parities of S
+        S lo[WIDE_K][2], hi[WIDE_K][2];
+#pragma unroll
+        for (int cand = 0; cand < WIDE_K; cand++) {
+            exc[cand] = grid_shfl_up(inc[cand], 1);
+            if (lane == 0) exc[cand].a0 = exc[cand].a1 = 0;
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                S q = p ? exc[cand].a1 : exc[cand].a0;
+                lo[cand][p] = hi[cand][p] = q + st[cand][0].floor_i;
+#pragma unroll
+                for (int k = 0; k < WIDE_EPL; k++) {
+                    const S tf = q + st[cand][k].floor_i;
+                    lo[cand][p] = tf < lo[cand][p] ? tf : lo[cand][p];
+                    hi[cand][p] = tf > hi[cand][p] ? tf : hi[cand][p];
+                    q += ((p + (int)(q & 1)) & 1) ? st[cand][k].step[1] : st[cand][k].step[0];      // (a select: an index would send st[] to scratch memory)
+                }
+                lo[cand][p] = wide_clamp<T>(lo[cand][p]);
+                hi[cand][p] = wide_clamp<T>(hi[cand][p]);
+            }
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+            for (int cand = 0; cand < WIDE_K; cand++) {
+#pragma unroll
+                for (int p = 0; p < 2; p++) {
+                    const S ol = grid_lane(lo[cand][p], (int)(lane ^ (uint32_t)d)), oh = grid_lane(hi[cand][p], (int)(lane ^ (uint32_t)d));
+                    lo[cand][p] = ol < lo[cand][p] ? ol : lo[cand][p];
+                    hi[cand][p] = oh > hi[cand][p] ? oh : hi[cand][p];
+                }
+            }
+        }
+        uint32_t bad = 0;
+#pragma unroll
+        for (int cand = 0; cand < WIDE_K; cand++) {
+            if (__ballot((cross >> cand) & 1u) != 0) bad |= (1u << cand) | wide_bad_sub(cand, wave);
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int cand = 0; cand < WIDE_K; cand++) {
+                WideSum<S> w;
+                w.of[0].step = inc[cand].a0; w.of[1].step = inc[cand].a1;
+                w.of[0].lo = lo[cand][0]; w.of[1].lo = lo[cand][1];
+                w.of[0].hi = hi[cand][0]; w.of[1].hi = hi[cand][1];
+                w.of[0].e = w.of[1].e = ((head.bad | bad) >> cand) & 1u ? WIDE_NO_E(S) : (S)(head.e0 + cand);
+                s_sub[cand * WIDE_SUBS + wave] = w;
+            }
+            if (bad) atomicOr(&s_bad, bad);
+        }
+        __syncthreads();
+        if (t < WIDE_K * WIDE_SUBS) ws.subs[c * (WIDE_K * WIDE_SUBS) + t] = s_sub[t];
+        if (t < WIDE_K) {
+            // (thread `cand` puts candidate `cand`'s sub-chunks together)
+            WideSum<S> out = s_sub[t * WIDE_SUBS];
+            for (uint32_t w = 1; w < WIDE_SUBS; w++) out = wide_then<T>(out, s_sub[t * WIDE_SUBS + w]);
+            ws.maps[c * WIDE_K + t] = out;
+            if (t == 1) {
+                // Is the walk likely to open this chunk?  Candidate 1 is the exponent of the rough sum
+                // in front: the walk's own test on that sum, with a margin for how far the exact chain
+                // may be from it.  (Only a hint: the walk loads hinted chunks ahead of time.)
+                bool hint = ((head.bad | s_bad) & 2u) != 0;
+                if (!hint) {
+                    const S sa = (S)scalbn(a, G::MANT - (head.e0 + 1));
+                    const S margin = (S)1 << (G::MANT - 8);
+                    for (int p = 0; p < 2; p++) hint = hint || !wide_inside<T>(sa + out.of[p].lo, sa + out.of[p].hi, margin);
+                }
+                if (hint) atomicOr(&s_bad, WIDE_HINT);
+            }
+        }
+        __syncthreads();
+        head.bad |= s_bad;
     }
+    else if (t < WIDE_K * (1 + WIDE_SUBS)) {
+        // no candidate at all (the sum in front is zero or not finite, the last, partial chunk): the
+        // walk reads the summaries before anything else, so they have to say so themselves
+        WideSum<S> none;
+        for (int p = 0; p < 2; p++) { none.of[p].lo = none.of[p].hi = none.of[p].step = 0; none.of[p].e = WIDE_NO_E(S); }
+        if (t < WIDE_K) ws.maps[c * WIDE_K + t] = none;
+        else ws.subs[c * (WIDE_K * WIDE_SUBS) + (t - WIDE_K)] = none;
+    }
+    if ((head.bad & WIDE_CHUNK_BITS) == WIDE_CHUNK_BITS) head.bad |= WIDE_HINT;
     if (t == 0) ws.heads[c] = head;
 }
 
 // ---- pass 3: the chunks in order ---------------------------------------------------------------------
-template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok)
+// acc's exponent if acc is a normal number
+template <typename T> __device__ __forceinline__ bool wide_exponent(T acc, int &e)
+{
+    typedef Grid<T> G;
+    typedef typename G::U U;
+    const int aef = (int)(((U)to_bits<T>(acc) >> G::MANT) & (U)G::EMASK);
+    e = aef - G::BIAS;
+    return aef != 0 && aef != G::EMASK;
+}
+
+// one side out of LDS, in 128-bit reads
+__device__ __forceinline__ WideSide<int32_t> wide_side(const WideSide<int32_t> *p)
+{
+    typedef int32_t v4 __attribute__((ext_vector_type(4)));
+    const v4 v = *(const v4 *)p;
+    WideSide<int32_t> r;
+    r.lo = v.x; r.hi = v.y; r.step = v.z; r.e = v.w;
+    return r;
+}
+__device__ __forceinline__ WideSide<int64_t> wide_side(const WideSide<int64_t> *p)
+{
+    typedef int64_t v2 __attribute__((ext_vector_type(2)));
+    const v2 a = ((const v2 *)p)[0], b = ((const v2 *)p)[1];
+    WideSide<int64_t> r;
+    r.lo = a.x; r.hi = a.y; r.step = b.x; r.e = b.y;
+    return r;
+}
+
+// The three candidates' summaries of one run of packets (w, w + stride, w + 2 * stride) against the
+// actual sum: if one of them is for acc's exponent and every exact partial sum stays inside acc's
+// binade, acc takes the whole step and the answer is true.  All three are read at once, before it is
+// known which one counts: one trip to LDS on the chain from sum to sum.
+template <typename T> __device__ __forceinline__ bool wide_take(T &acc, const WideSum<typename Grid<T>::S> *w, uint32_t stride)
 {
     typedef Grid<T> G;
     typedef typename G::U U;
     typedef typename G::S S;
+    static_assert(WIDE_K == 3, "three candidates are read here");
+    int e;
+    if (!wide_exponent<T>(acc, e)) return false;
+    const U ab = (U)to_bits<T>(acc);
+    const U afrac = (ab & (((U)1 << G::MANT) - 1)) | ((U)1 << G::MANT);
+    const S s0 = (ab >> (sizeof(U) * 8 - 1)) ? -(S)afrac : (S)afrac;
+    const int p = (int)(s0 & 1);
+    const WideSide<S> c0 = wide_side(&w[0].of[p]), c1 = wide_side(&w[stride].of[p]), c2 = wide_side(&w[2 * stride].of[p]);
+    const bool i0 = c0.e == (S)e, i1 = c1.e == (S)e, i2 = c2.e == (S)e;
+    if (!(i0 || i1 || i2)) return false;
+    const S lo = i0 ? c0.lo : (i1 ? c1.lo : c2.lo), hi = i0 ? c0.hi : (i1 ? c1.hi : c2.hi), step = i0 ? c0.step : (i1 ? c1.step : c2.step);
+    if (!wide_inside<T>(s0 + lo, s0 + hi, (S)0)) return false;
+    const S sum = s0 + step;
+    acc = from_bits<T>((uint64_t)(((U)(e + G::BIAS) << G::MANT) | ((U)(sum < 0 ? -sum : sum) & (((U)1 << G::MANT) - 1)) |
+                                  (sum < 0 ? (U)1 << (sizeof(U) * 8 - 1) : (U)0)));
+    return true;
+}
+
+// A chunk the walk could not take in one step (one wavefront; the chunk's packets in s_val, its
+// sub-chunk summaries in s_sub): sub-chunk by sub-chunk, each in one step where its test holds for the
+// sum in front of it, the plain way otherwise.  Sub-chunks that no sum can take in one step (every
+// candidate crossed out) are added in one go with their neighbours.
+template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len)
+{
+    uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate
+#pragma unroll
+    for (int cand = 0; cand < WIDE_K; cand++) forced &= head.bad >> (4 + cand * WIDE_SUBS);
+    uint32_t w = 0;
+    while (w * 64u * WIDE_EPL < len) {
+        const uint32_t at = w * 64u * WIDE_EPL;
+        if (!((forced >> w) & 1u) && len - at >= 64u * WIDE_EPL) {
+            if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; continue; }
+            acc = plain_fold<T>(acc, s_val + at, 64u * WIDE_EPL);
+            w++;
+            continue;
+        }
+        uint32_t w1 = w + 1;
+        while (w1 < WIDE_SUBS && ((forced >> w1) & 1u)) w1++;
+        const uint32_t end = w1 * 64u * WIDE_EPL < len ? w1 * 64u * WIDE_EPL : len;
+        acc = plain_fold<T>(acc, s_val + at, end - at);
+        w = w1;
+    }
+    return acc;
+}
+
+// the first hinted chunk of a stage (a bit per chunk in h0, h1) at or behind `from`; m if there is none
+__device__ __forceinline__ uint32_t wide_next_hint(uint64_t h0, uint64_t h1, uint32_t from, uint32_t m)
+{
+    if (from < 64) h0 &= ~(uint64_t)0 << from;
+    else { h0 = 0; h1 = from < 128 ? h1 & (~(uint64_t)0 << (from - 64)) : 0; }
+    return h0 ? (uint32_t)__ffsll((unsigned long long)h0) - 1u : (h1 ? 63u + (uint32_t)__ffsll((unsigned long long)h1) : m);
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok)
+{
+    typedef Grid<T> G;
+    typedef typename G::S S;
+    constexpr uint32_t SUB_DW = (uint32_t)(sizeof(WideSum<S>) * WIDE_K * WIDE_SUBS / 4);     // a chunk's sub-chunk summaries, in 32-bit words
+    static_assert(SUB_DW <= WIDE_TPB && WIDE_STAGE <= WIDE_TPB && WIDE_STAGE == 128, "one word / one head per thread, two 64-bit hint masks");
     __shared__ __align__(16) T s_val[WIDE_CHUNK + 64];          // (slack: the plain fold reads a batch ahead)
     __shared__ WideHead s_head[WIDE_STAGE];
     __shared__ WideSum<S> s_map[WIDE_STAGE * WIDE_K];
+    __shared__ __align__(16) WideSum<S> s_sub[WIDE_K * WIDE_SUBS];
+    __shared__ uint64_t s_hint[WIDE_STAGE / 64];
     __shared__ T s_acc;
     __shared__ int32_t s_cnt;
     WideWs<T> ws(ws_base, nc);
@@ -228,81 +420,74 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
     if (t == 0) s_cnt = 0;
     T acc = (T)0;                                               // the same in every lane
 #ifdef WIDE_DEBUG
-    uint32_t nplain = 0;
+    uint32_t nplain = 0, nmiss = 0;
 #endif
-    const S LO = (S)1 << G::MANT, HI = ((S)1 << (G::MANT + 1)) - 2;
-    T ahead[WIDE_EPL];                                          // a chunk's packets, loaded ahead
+    // A chunk's packets and sub-chunk summaries, loaded ahead of the walk: an opened chunk costs little
+    // once its packets are at hand, and most of a microsecond of waiting if they are not.
+    T ahead[WIDE_EPL];
+    uint32_t sub_ahead = 0;
     uint64_t ahead_of = ~(uint64_t)0;
+#define WIDE_FETCH(cc_) do { \
+        const uint64_t fc_ = (cc_), f0_ = fc_ * WIDE_CHUNK; \
+        _Pragma("unroll") for (int k = 0; k < WIDE_EPL; k++) { \
+            const uint64_t i = f0_ + (uint32_t)k * WIDE_TPB + t; \
+            int32_t unused = 0; \
+            ahead[k] = wide_value<OP, T>(in, i < in.n ? i : in.n - 1, &unused); \
+        } \
+        if (t < SUB_DW) sub_ahead = ((const uint32_t *)(ws.subs + fc_ * (WIDE_K * WIDE_SUBS)))[t]; \
+        ahead_of = fc_; \
+    } while (0)
     for (uint64_t c0 = 0; c0 < nc; c0 += WIDE_STAGE) {
         const uint32_t m = (uint32_t)(nc - c0 < WIDE_STAGE ? nc - c0 : WIDE_STAGE);
         __syncthreads();
         for (uint32_t j = t; j < m; j += WIDE_TPB) s_head[j] = ws.heads[c0 + j];
         for (uint32_t j = t; j < m * WIDE_K; j += WIDE_TPB) s_map[j] = ws.maps[c0 * WIDE_K + j];
+        if (t < WIDE_STAGE) {
+            const uint64_t b = __ballot(t < m && (ws.heads[c0 + (t < m ? t : 0)].bad & WIDE_HINT) != 0);
+            if (lane == 0) s_hint[wave] = b;
+        }
         __syncthreads();
+        const uint64_t hint0 = s_hint[0], hint1 = s_hint[1];
+        {
+            uint32_t nx;
+            nx = wide_next_hint(hint0, hint1, 0u, m);
+            if (nx < m && ahead_of != c0 + nx) WIDE_FETCH(c0 + nx);
+        }
         for (uint32_t j = 0; j < m; j++) {
-            const U ab = (U)to_bits<T>(acc);
-            const int aef = (int)((ab >> G::MANT) & (U)G::EMASK);
+            if (wide_take<T>(acc, &s_map[j * WIDE_K], 1u)) continue;        // (uniform: acc is the same in every lane)
             const WideHead head = s_head[j];
-            bool done = false;
-            if (aef != 0 && aef != G::EMASK) {
-                const int e = aef - G::BIAS, cand = e - head.e0;
-                if (cand >= 0 && cand < WIDE_K && !((head.bad >> cand) & 1u)) {
-                    const U afrac = (ab & (((U)1 << G::MANT) - 1)) | ((U)1 << G::MANT);
-                    const S s0 = (ab >> (sizeof(U) * 8 - 1)) ? -(S)afrac : (S)afrac;
-                    const int p = (int)(s0 & 1);
-                    const WideSum<S> *w = &s_map[j * WIDE_K + (uint32_t)cand];      // (read in place: a copy indexed by p would live in scratch memory)
-                    const S l = s0 + w->lo[p], h = s0 + w->hi[p];
-                    // every exact partial sum of the chunk inside the binade (the same conservative
-                    // ends as grid_inside), all on one side of zero
-                    if ((l >= LO && h <= HI) || (h <= -LO - 1 && l >= -HI)) {
-                        const S sum = s0 + w->step[p];
-                        acc = from_bits<T>((uint64_t)(((U)(e + G::BIAS) << G::MANT) | ((U)(sum < 0 ? -sum : sum) & (((U)1 << G::MANT) - 1)) |
-                                                      (sum < 0 ? (U)1 << (sizeof(U) * 8 - 1) : (U)0)));
-                        done = true;
-                    }
-                }
-            }
-            if (done) continue;                                 // (uniform: acc is the same in every lane)
-#ifdef WIDE_DEBUG
-            nplain++;
-#endif
-            // the chunk's packets the plain way: staged by everybody, added up by one wavefront.  The
-            // next chunk's packets are asked for before the adding starts: if that chunk has to be
-            // taken the plain way too (runs of them are the rule: zeros, non-finite sums, a sum that
-            // hovers), its values are in registers by the time this one is done.
+            // Opened: staged by everybody, gone through by one wavefront.
             const uint64_t cc = c0 + j, first = cc * WIDE_CHUNK;
             const uint32_t len = (uint32_t)(in.n - first < WIDE_CHUNK ? in.n - first : WIDE_CHUNK);
-            if (ahead_of != cc) {
-#pragma unroll
-                for (int k = 0; k < WIDE_EPL; k++) {
-                    const uint64_t i = first + (uint32_t)k * WIDE_TPB + t;
-                    int32_t unused = 0;
-                    ahead[k] = wide_value<OP, T>(in, i < in.n ? i : in.n - 1, &unused);
-                }
-            }
+#ifdef WIDE_DEBUG
+            nplain++;
+            if (ahead_of != cc) nmiss++;
+#endif
+            if (ahead_of != cc) WIDE_FETCH(cc);
             __syncthreads();
 #pragma unroll
             for (int k = 0; k < WIDE_EPL; k++) s_val[(uint32_t)k * WIDE_TPB + t] = ahead[k];
+            if (t < SUB_DW) ((uint32_t *)s_sub)[t] = sub_ahead;
             __syncthreads();
-            if (cc + 1 < nc) {
-#pragma unroll
-                for (int k = 0; k < WIDE_EPL; k++) {
-                    const uint64_t i = first + WIDE_CHUNK + (uint32_t)k * WIDE_TPB + t;
-                    int32_t unused = 0;
-                    ahead[k] = wide_value<OP, T>(in, i < in.n ? i : in.n - 1, &unused);
-                }
-                ahead_of = cc + 1;
+            // What to load next, before the adding starts: the next hinted chunk if the hints are holding
+            // (this chunk was one), the chunk behind this one if not (runs of opened chunks are the rule
+            // where the rough sums mislead).
+            {
+                uint32_t nx = j + 1;
+                if (head.bad & WIDE_HINT) nx = wide_next_hint(hint0, hint1, j + 1, m);
+                if (nx < m) WIDE_FETCH(c0 + nx);
             }
             if (wave == 0) {
-                acc = plain_fold<T>(acc, s_val, len);           // (values behind len are staged but not added)
+                acc = wide_open<T>(acc, head, s_sub, s_val, len);       // (values behind len are staged but not added)
                 if (lane == 0) s_acc = acc;
             }
             __syncthreads();
             acc = s_acc;
         }
     }
+#undef WIDE_FETCH
 #ifdef WIDE_DEBUG
-    if (t == 0) printf("wide walk: %u of %llu chunks plain\n", nplain, (unsigned long long)nc);
+    if (t == 0) printf("wide walk: %u of %llu chunks opened, %u of them not loaded ahead\n", nplain, (unsigned long long)nc, nmiss);
 #endif
     int32_t cnt = 0;
     if (OP == MRPDR_AVG) {

@@ -74,6 +74,18 @@ def datasets(dt, n, seed):
     out["non_finite"] = f
     out["bit_patterns"] = random_values(dt, n, seed + 8, finite=False)
     out["finite_bit_patterns"] = random_values(dt, n, seed + 9)
+    # excursions: from a sum near 1.5, a run of +3.99 far out of the sum's binade and back again, the
+    # run's length chosen so that the partial sums, counted in units of the starting sum's last
+    # place, come within a hair of what a signed integer of the element's width holds (float: 64
+    # packets of 3.99 are 2^31 - 0.6 * 2^23 units; double: 513 are 2^63 - 1.1 * 2^52).  At every
+    # chunk start of the device-wide form and in between.
+    k = 64 if dt.itemsize == 4 else 513
+    x = np.zeros(n)
+    x[0] = 1.5
+    for at in range(1024, n - 2 * k, 1024 + 2 * k + 37 if dt.itemsize == 4 else 2048):
+        x[at:at + k] = 3.99
+        x[at + k:at + 2 * k] = -3.99
+    out["excursion"] = x.astype(dt)
     # overflow to infinity and what follows
     big = (np.finfo(dt).max / 4.0 * (0.5 + u)).astype(dt)
     out["overflow"] = big
