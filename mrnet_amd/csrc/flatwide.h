@@ -50,6 +50,7 @@ struct WideHead { int32_t e0; uint32_t bad; };
 #define WIDE_HINT 0x80000000u
 #define WIDE_CHUNK_BITS ((1u << WIDE_K) - 1u)
 #define WIDE_ALL_BAD ((1u << (4 + WIDE_K * WIDE_SUBS)) - 1u)
+#define WIDE_SUB_BITS (WIDE_ALL_BAD & ~15u)
 __host__ __device__ constexpr uint32_t wide_bad_sub(int cand, uint32_t w) { return 1u << (4 + cand * WIDE_SUBS + (int)w); }
 __host__ __device__ constexpr uint32_t wide_bad_all_of(int cand) { return (1u << cand) | (((1u << WIDE_SUBS) - 1u) << (4 + cand * WIDE_SUBS)); }
 
@@ -83,6 +84,27 @@ template <int OP, typename T> __device__ __forceinline__ T wide_value(const Filt
         v = mul_cnt<T>(v, c);
         *cnt += c;
     }
+    return v;
+}
+
+// A packet as it lies in memory -- its value, its count for AVG, its byte order if the wave carries
+// one per packet -- and what the fold makes of it.  Two steps, so that loads issued ahead of time stay
+// in flight: turning the bytes round right behind the load would wait for it.
+template <typename T> struct WideRaw { typename UIntOf<sizeof(T)>::type v; uint32_t c; uint8_t o; };
+template <int OP, typename T> __device__ __forceinline__ WideRaw<T> wide_load(const FilterIn &in, uint64_t i)
+{
+    WideRaw<T> r;
+    r.v = ld_u<typename UIntOf<sizeof(T)>::type>(in.values + i * in.value_stride);
+    r.c = 0; r.o = 0;
+    if (OP == MRPDR_AVG) r.c = ld_u<uint32_t>(in.counts + i * in.count_stride);
+    if (in.orders) r.o = in.orders[i];
+    return r;
+}
+template <int OP, typename T> __device__ __forceinline__ T wide_value_of(const FilterIn &in, const WideRaw<T> &r)
+{
+    const bool swap = in.orders ? r.o != 0 : in.swap != 0;
+    T v = from_bits<T>((uint64_t)(swap ? bswap_u(r.v) : r.v));
+    if (OP == MRPDR_AVG) v = mul_cnt<T>(v, (int32_t)(swap ? bswap_u(r.c) : r.c));
     return v;
 }
 
@@ -175,10 +197,9 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_ba
     if (t == 0) s_bad = 0;
     const bool whole = (c + 1) * WIDE_CHUNK <= in.n;            // (the last, partial chunk is folded plainly)
     // the chunk's packets first: their loads are in flight while the sums in front are added up
-    T x[WIDE_EPL];
-    int32_t unused = 0;
+    WideRaw<T> raw[WIDE_EPL];
 #pragma unroll
-    for (int k = 0; k < WIDE_EPL; k++) x[k] = whole ? wide_value<OP, T>(in, c * WIDE_CHUNK + t * WIDE_EPL + (uint32_t)k, &unused) : (T)0;
+    for (int k = 0; k < WIDE_EPL; k++) raw[k] = wide_load<OP, T>(in, whole ? c * WIDE_CHUNK + t * WIDE_EPL + (uint32_t)k : 0);
     // the sum in front of the chunk, roughly
     double a = 0;
     for (uint64_t j = t; j < c; j += WIDE_TPB) a += ws.sums[j];
@@ -200,6 +221,9 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_ba
         // The candidates side by side, not one after the other: three independent chains of shuffles.
         // (A candidate already marked bad is computed as well and not looked at.)  Every wavefront
         // sums up its own 256 packets, relative to the first of them.
+        T x[WIDE_EPL];
+#pragma unroll
+        for (int k = 0; k < WIDE_EPL; k++) x[k] = wide_value_of<OP, T>(in, raw[k]);
         GridStep<T> st[WIDE_K][WIDE_EPL];
         GridMap<S> inc[WIDE_K], exc[WIDE_K];
         uint32_t cross = 0;
@@ -369,8 +393,9 @@ template <typename T> __device__ __forceinline__ bool wide_take(T &acc, const Wi
 // A chunk the walk could not take in one step (one wavefront; the chunk's packets in s_val, its
 // sub-chunk summaries in s_sub): sub-chunk by sub-chunk, each in one step where its test holds for the
 // sum in front of it, the plain way otherwise.  Sub-chunks that no sum can take in one step (every
-// candidate crossed out) are added in one go with their neighbours.
-template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len)
+// candidate crossed out) are added in one go with their neighbours.  `taken` counts the sub-chunks
+// that went in one step.
+template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len, uint32_t &taken)
 {
     uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate
 #pragma unroll
@@ -379,7 +404,7 @@ template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHe
     while (w * 64u * WIDE_EPL < len) {
         const uint32_t at = w * 64u * WIDE_EPL;
         if (!((forced >> w) & 1u) && len - at >= 64u * WIDE_EPL) {
-            if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; continue; }
+            if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; taken++; continue; }
             acc = plain_fold<T>(acc, s_val + at, 64u * WIDE_EPL);
             w++;
             continue;
@@ -424,15 +449,15 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
 #endif
     // A chunk's packets and sub-chunk summaries, loaded ahead of the walk: an opened chunk costs little
     // once its packets are at hand, and most of a microsecond of waiting if they are not.
-    T ahead[WIDE_EPL];
+    WideRaw<T> ahead[WIDE_EPL];
+    uint32_t dry = 0, skipped = 0;                              // (wavefront 0's: opened chunks in a row without a sub-chunk taken in one step)
     uint32_t sub_ahead = 0;
     uint64_t ahead_of = ~(uint64_t)0;
 #define WIDE_FETCH(cc_) do { \
         const uint64_t fc_ = (cc_), f0_ = fc_ * WIDE_CHUNK; \
         _Pragma("unroll") for (int k = 0; k < WIDE_EPL; k++) { \
             const uint64_t i = f0_ + (uint32_t)k * WIDE_TPB + t; \
-            int32_t unused = 0; \
-            ahead[k] = wide_value<OP, T>(in, i < in.n ? i : in.n - 1, &unused); \
+            ahead[k] = wide_load<OP, T>(in, i < in.n ? i : in.n - 1); \
         } \
         if (t < SUB_DW) sub_ahead = ((const uint32_t *)(ws.subs + fc_ * (WIDE_K * WIDE_SUBS)))[t]; \
         ahead_of = fc_; \
@@ -466,7 +491,7 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
             if (ahead_of != cc) WIDE_FETCH(cc);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < WIDE_EPL; k++) s_val[(uint32_t)k * WIDE_TPB + t] = ahead[k];
+            for (int k = 0; k < WIDE_EPL; k++) s_val[(uint32_t)k * WIDE_TPB + t] = wide_value_of<OP, T>(in, ahead[k]);
             if (t < SUB_DW) ((uint32_t *)s_sub)[t] = sub_ahead;
             __syncthreads();
             // What to load next, before the adding starts: the next hinted chunk if the hints are holding
@@ -478,7 +503,17 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
                 if (nx < m) WIDE_FETCH(c0 + nx);
             }
             if (wave == 0) {
-                acc = wide_open<T>(acc, head, s_sub, s_val, len);       // (values behind len are staged but not added)
+                // (values behind len are staged but not added)
+                // Trying the sub-chunks costs about a third of adding them: where the last chunks opened
+                // had none that went in one step (data that jumps between binades from packet to packet),
+                // the next ones are added whole, and every eighth tries again.
+                const bool hopeless = (head.bad & WIDE_SUB_BITS) == WIDE_SUB_BITS;     // every sub-chunk crossed out for every candidate
+                if (hopeless || (dry >= 2 && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val, len);
+                else {
+                    uint32_t taken = 0;
+                    acc = wide_open<T>(acc, head, s_sub, s_val, len, taken);
+                    dry = taken ? 0 : dry + 1;
+                }
                 if (lane == 0) s_acc = acc;
             }
             __syncthreads();

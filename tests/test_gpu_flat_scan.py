@@ -86,6 +86,9 @@ def datasets(dt, n, seed):
         x[at:at + k] = 3.99
         x[at + k:at + 2 * k] = -3.99
     out["excursion"] = x.astype(dt)
+    y = -x
+    y[0] = -1.99                                                    # (the other side of zero, a sum near its binade's end)
+    out["excursion_negative"] = y.astype(dt)
     # overflow to infinity and what follows
     big = (np.finfo(dt).max / 4.0 * (0.5 + u)).astype(dt)
     out["overflow"] = big
