@@ -31,6 +31,7 @@
 #define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
+#define WIDE_MANY_MIN 4u                // chunks the hints promise in a row from which the walk takes them many at a time
 
 #define WIDE_SUBS (WIDE_TPB / 64)        // a wavefront's packets (256) are a sub-chunk with summaries of its own
 static_assert(WIDE_TPB * WIDE_EPL == WIDE_CHUNK && 4 + WIDE_K * WIDE_SUBS <= 31, "head.bad holds a bit per candidate and sub-chunk");
@@ -345,6 +346,15 @@ template <typename T> __device__ __forceinline__ bool wide_exponent(T acc, int &
     return aef != 0 && aef != G::EMASK;
 }
 
+// the number of exponent e (a normal number's) and signed integer significand sum (2^MANT <= |sum| < 2^(MANT+1))
+template <typename T> __device__ __forceinline__ T wide_number(int e, typename Grid<T>::S sum)
+{
+    typedef Grid<T> G;
+    typedef typename G::U U;
+    return from_bits<T>((uint64_t)(((U)(e + G::BIAS) << G::MANT) | ((U)(sum < 0 ? -sum : sum) & (((U)1 << G::MANT) - 1)) |
+                                   (sum < 0 ? (U)1 << (sizeof(U) * 8 - 1) : (U)0)));
+}
+
 // one side out of LDS, in 128-bit reads
 __device__ __forceinline__ WideSide<int32_t> wide_side(const WideSide<int32_t> *p)
 {
@@ -384,10 +394,70 @@ template <typename T> __device__ __forceinline__ bool wide_take(T &acc, const Wi
     if (!(i0 || i1 || i2)) return false;
     const S lo = i0 ? c0.lo : (i1 ? c1.lo : c2.lo), hi = i0 ? c0.hi : (i1 ? c1.hi : c2.hi), step = i0 ? c0.step : (i1 ? c1.step : c2.step);
     if (!wide_inside<T>(s0 + lo, s0 + hi, (S)0)) return false;
-    const S sum = s0 + step;
-    acc = from_bits<T>((uint64_t)(((U)(e + G::BIAS) << G::MANT) | ((U)(sum < 0 ? -sum : sum) & (((U)1 << G::MANT) - 1)) |
-                                  (sum < 0 ? (U)1 << (sizeof(U) * 8 - 1) : (U)0)));
+    acc = wide_number<T>(e, s0 + step);
     return true;
+}
+
+// lane l's value, l the same in every lane: the answer is known to be the same in every lane too
+// (a shuffle's is not, and everything computed from it -- the sum, the walk's branches -- would be
+// carried out per lane)
+__device__ __forceinline__ int32_t wide_of_lane(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
+__device__ __forceinline__ int64_t wide_of_lane(int64_t v, uint32_t l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), (int)l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// A run of chunks at once (w: the first one's summaries, WIDE_K per chunk; avail: how many there are):
+// lane l takes the summary of chunk l that is for acc's exponent, the lanes' summaries are put together
+// by an inclusive scan (wide_then is associative; a chunk without a summary for the exponent stands as
+// one that fails), and lane l's result says whether chunks 0 .. l all go in one step each from the
+// sum as it is.  acc takes the steps of the first chunks that do; the answer is how many those were
+// (the chunk behind them, if there is one, failed its test).  About four single steps' worth of
+// instructions, whatever the run's length.
+template <typename T> __device__ __forceinline__ uint32_t wide_take_many(T &acc, const WideSum<typename Grid<T>::S> *w, uint32_t avail, uint32_t lane)
+{
+    typedef Grid<T> G;
+    typedef typename G::U U;
+    typedef typename G::S S;
+    int e;
+    if (!wide_exponent<T>(acc, e)) return 0;
+    const U ab = (U)to_bits<T>(acc);
+    const U afrac = (ab & (((U)1 << G::MANT) - 1)) | ((U)1 << G::MANT);
+    const S s0 = (ab >> (sizeof(U) * 8 - 1)) ? -(S)afrac : (S)afrac;
+    const bool odd = (s0 & 1) != 0;
+    const S FAILS = (S)1 << (G::MANT + 3);                      // (wide_clamp's bound: inside no binade)
+    // (plain variables, no structures: a structure copied under a condition ends up in scratch memory)
+    S lo0 = -FAILS, hi0 = FAILS, st0 = 0, lo1 = -FAILS, hi1 = FAILS, st1 = 0;      // in front of an even / an odd S
+    if (lane < avail) {
+        const WideSum<S> *c = w + lane * WIDE_K;
+#pragma unroll
+        for (int k = 0; k < WIDE_K; k++) {
+            const WideSide<S> even = wide_side(&c[k].of[0]), odd_side = wide_side(&c[k].of[1]);
+            const bool is = even.e == (S)e;
+            lo0 = is ? even.lo : lo0; hi0 = is ? even.hi : hi0; st0 = is ? even.step : st0;
+            lo1 = is ? odd_side.lo : lo1; hi1 = is ? odd_side.hi : hi1; st1 = is ? odd_side.step : st1;
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        // the run of chunks ending d lanes down (a), this lane's run behind it (b): as wide_then
+        const S alo0 = grid_up(lo0, d), ahi0 = grid_up(hi0, d), ast0 = grid_up(st0, d);
+        const S alo1 = grid_up(lo1, d), ahi1 = grid_up(hi1, d), ast1 = grid_up(st1, d);
+        const bool odd0 = (ast0 & 1) != 0, odd1 = (ast1 & 1) == 0;      // the parity of S + a's step, S even / odd
+        const S bl0 = ast0 + (odd0 ? lo1 : lo0), bh0 = ast0 + (odd0 ? hi1 : hi0), bs0 = ast0 + (odd0 ? st1 : st0);
+        const S bl1 = ast1 + (odd1 ? lo1 : lo0), bh1 = ast1 + (odd1 ? hi1 : hi0), bs1 = ast1 + (odd1 ? st1 : st0);
+        if ((int)lane >= d) {
+            lo0 = wide_clamp<T>(alo0 < bl0 ? alo0 : bl0); hi0 = wide_clamp<T>(ahi0 > bh0 ? ahi0 : bh0); st0 = bs0;
+            lo1 = wide_clamp<T>(alo1 < bl1 ? alo1 : bl1); hi1 = wide_clamp<T>(ahi1 > bh1 ? ahi1 : bh1); st1 = bs1;
+        }
+    }
+    const S lo = odd ? lo1 : lo0, hi = odd ? hi1 : hi0, step = odd ? st1 : st0;
+    const uint64_t ok = __ballot(wide_inside<T>(s0 + lo, s0 + hi, (S)0));
+    const uint32_t took = ~ok ? (uint32_t)__ffsll((unsigned long long)~ok) - 1u : 64u;
+    if (took) acc = wide_number<T>(e, s0 + wide_of_lane(step, took - 1u));
+    return took;
 }
 
 // A chunk the walk could not take in one step (one wavefront; the chunk's packets in s_val, its
@@ -473,13 +543,17 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
         }
         __syncthreads();
         const uint64_t hint0 = s_hint[0], hint1 = s_hint[1];
-        {
-            uint32_t nx;
-            nx = wide_next_hint(hint0, hint1, 0u, m);
-            if (nx < m && ahead_of != c0 + nx) WIDE_FETCH(c0 + nx);
-        }
+        uint32_t calm = wide_next_hint(hint0, hint1, 0u, m);       // the next chunk that is likely to be opened
+        if (calm < m && ahead_of != c0 + calm) WIDE_FETCH(c0 + calm);
         for (uint32_t j = 0; j < m; j++) {
-            if (wide_take<T>(acc, &s_map[j * WIDE_K], 1u)) continue;        // (uniform: acc is the same in every lane)
+            // (uniform: acc is the same in every lane)
+            if (j > calm) calm = wide_next_hint(hint0, hint1, j, m);
+            if (calm > j && calm - j >= WIDE_MANY_MIN) {
+                const uint32_t took = wide_take_many<T>(acc, &s_map[j * WIDE_K], m - j, lane);
+                j += took;
+                if (took == 64u || j >= m) { j--; continue; }
+            }
+            else if (wide_take<T>(acc, &s_map[j * WIDE_K], 1u)) continue;
             const WideHead head = s_head[j];
             // Opened: staged by everybody, gone through by one wavefront.
             const uint64_t cc = c0 + j, first = cc * WIDE_CHUNK;
