@@ -443,7 +443,9 @@ int32_t mrpdr_wave_decode_filter(mrpdr_ctx *ctx, const mrpdr_fmt *f, const mrpdr
  * reference.)  Same arguments and results as mrpdr_wave_filter, bit for bit, minus the ctx: the
  * nodes the two launches hand over live in a device array built into the library (256 KiB, held by
  * every GPU the library runs on until the process ends), so the call makes no hipMalloc / hipFree
- * and needs no workspace.  Limits: n <= 2^24 packets (FALSE beyond); the kernels run on the calling
+ * and needs no workspace.  (The array also takes the chunk summaries of a flat float / double SUM or
+ * AVG, for up to 536,000 float or 273,000 double packets; larger flat float folds fall back to the
+ * one-workgroup scan: same bits, slower.)  Limits: n <= 2^24 packets (FALSE beyond); the kernels run on the calling
  * thread's current device, where all pointers must live; all calls on one GPU share that GPU's
  * array, so two calls that overlap in time on one GPU (different streams or threads) race --
  * serialise them.  The first call on a device resolves the array's address
