@@ -21,7 +21,7 @@ CASES = [  # (operator, DataType, numpy dtype, shape)
     (W.TFILTER_MAX, W.DataType.INT16_T, np.int16, W.SHAPE_TREE),
     (W.TFILTER_AVG, W.DataType.INT64_T, np.int64, W.SHAPE_FLAT),
     (W.TFILTER_AVG, W.DataType.DOUBLE_T, np.float64, W.SHAPE_TREE),
-    (W.TFILTER_AVG, W.DataType.DOUBLE_T, np.float64, W.SHAPE_FLAT),      # (300,001 packets: chunk summaries in the built-in array)
+    (W.TFILTER_AVG, W.DataType.DOUBLE_T, np.float64, W.SHAPE_FLAT),      # (200,003 packets: chunk summaries in the built-in array; 300,001 doubles are beyond its room: the one-workgroup scan)
     (W.FILTER_OR, W.DataType.UINT64_T, np.uint64, W.SHAPE_TREE),
 ]
 
@@ -55,8 +55,8 @@ def both(codec, op, t, dt, shape, n, seed, swap):
 
 @pytest.mark.parametrize("op,t,dt,shape", CASES)
 def test_noalloc_filter_equals_ctx_filter_twice_in_a_row(codec, op, t, dt, shape):
-    # first a wave of many workgroup nodes, then a smaller one, then a tiny one
-    for n, seed, swap in ((300_001, 11, 0), (5_000, 12, 1), (3, 13, 0)):
+    # first a wave of many workgroup nodes, then smaller ones, then a tiny one
+    for n, seed, swap in ((300_001, 11, 0), (200_003, 14, 1), (5_000, 12, 1), (3, 13, 0)):
         (a, b), vals, cnts = both(codec, op, t, dt, shape, n, seed, swap)
         assert a == b, (op, int(t), shape, n)
         assert a[1] == 1
