@@ -326,9 +326,10 @@ def small_wave_extras(codec):
     out["node_wave_us_by_packets"] = sweep
     # what ONE reference filter call (the flat shape, the mirrors' default) costs where the order of
     # the additions matters -- a serial chain -- beside the declared tree; 65,536 packets each
-    vf = torch.randn(n, dtype=torch.float32, device=dev)
+    gx = torch.Generator(device=dev).manual_seed(20)        # (the zero-mean figure depends on the draw: 120-280 us between seeds)
+    vf = torch.randn(n, dtype=torch.float32, device=dev, generator=gx)
     rows64 = torch.empty((n, 12), dtype=torch.uint8, device=dev)
-    rows64[:, :8] = (torch.randn(n, dtype=torch.float64, device=dev) * 1e-4 + 1e-3).view(torch.uint8).view(n, 8)
+    rows64[:, :8] = (torch.randn(n, dtype=torch.float64, device=dev, generator=gx) * 1e-4 + 1e-3).view(torch.uint8).view(n, 8)
     rows64[:, 8:] = torch.ones(n, dtype=torch.int32, device=dev).view(torch.uint8).view(n, 4)
     p64 = rows64.data_ptr()
     for name, shape in (("flat", W.SHAPE_FLAT), ("tree", W.SHAPE_TREE)):
@@ -340,7 +341,7 @@ def small_wave_extras(codec):
             # the flat float results are the reference's chain of additions; large waves take it a binade
             # at a time with a scan.  What that buys depends on the data: a sum that grows (timings,
             # counts) stays in a binade for long stretches, a zero-mean one hovers around powers of two
-            vpos = torch.rand(n, dtype=torch.float32, device=dev)
+            vpos = torch.rand(n, dtype=torch.float32, device=dev, generator=gx)
             f_pos = codec.bind_filter(W.TFILTER_SUM, W.DataType.FLOAT_T, vpos.data_ptr(), 4, None, 0, n, 0, shape, res, rok)
             f_pos_chain = codec.bind_filter(W.TFILTER_SUM, W.DataType.FLOAT_T, vpos.data_ptr(), 4, None, 0, n, 0,
                                             W.SHAPE_FLAT_SERIAL, res, rok)

@@ -519,17 +519,25 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
 #endif
     // A chunk's packets and sub-chunk summaries, loaded ahead of the walk: an opened chunk costs little
     // once its packets are at hand, and most of a microsecond of waiting if they are not.
-    WideRaw<T> ahead[WIDE_EPL];
+    // Wavefront 0, the one that adds, takes no part in loading and staging: every instruction it issues
+    // is time on the chain.
+    constexpr uint32_t LOADERS = WIDE_TPB - 64, LEPL = (WIDE_CHUNK + LOADERS - 1) / LOADERS;
+    static_assert(SUB_DW <= LOADERS, "one word of the sub-chunk summaries per loading thread");
+    const uint32_t u = t - 64u;                                 // (loading threads: 0 .. LOADERS - 1)
+    WideRaw<T> ahead[LEPL];
     uint32_t dry = 0, skipped = 0;                              // (wavefront 0's: opened chunks in a row without a sub-chunk taken in one step)
     uint32_t sub_ahead = 0;
     uint64_t ahead_of = ~(uint64_t)0;
 #define WIDE_FETCH(cc_) do { \
         const uint64_t fc_ = (cc_), f0_ = fc_ * WIDE_CHUNK; \
-        _Pragma("unroll") for (int k = 0; k < WIDE_EPL; k++) { \
-            const uint64_t i = f0_ + (uint32_t)k * WIDE_TPB + t; \
-            ahead[k] = wide_load<OP, T>(in, i < in.n ? i : in.n - 1); \
+        if (wave != 0) { \
+            _Pragma("unroll") for (uint32_t k = 0; k < LEPL; k++) { \
+                const uint32_t at_ = k * LOADERS + u; \
+                const uint64_t i = f0_ + (at_ < WIDE_CHUNK ? at_ : WIDE_CHUNK - 1u); \
+                ahead[k] = wide_load<OP, T>(in, i < in.n ? i : in.n - 1); \
+            } \
+            if (u < SUB_DW) sub_ahead = ((const uint32_t *)(ws.subs + fc_ * (WIDE_K * WIDE_SUBS)))[u]; \
         } \
-        if (t < SUB_DW) sub_ahead = ((const uint32_t *)(ws.subs + fc_ * (WIDE_K * WIDE_SUBS)))[t]; \
         ahead_of = fc_; \
     } while (0)
     for (uint64_t c0 = 0; c0 < nc; c0 += WIDE_STAGE) {
@@ -565,8 +573,11 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
             if (ahead_of != cc) WIDE_FETCH(cc);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < WIDE_EPL; k++) s_val[(uint32_t)k * WIDE_TPB + t] = wide_value_of<OP, T>(in, ahead[k]);
-            if (t < SUB_DW) ((uint32_t *)s_sub)[t] = sub_ahead;
+            for (uint32_t k = 0; k < LEPL; k++) {
+                const uint32_t at = k * LOADERS + u;
+                if (wave != 0 && at < WIDE_CHUNK) s_val[at] = wide_value_of<OP, T>(in, ahead[k]);
+            }
+            if (wave != 0 && u < SUB_DW) ((uint32_t *)s_sub)[u] = sub_ahead;
             __syncthreads();
             // What to load next, before the adding starts: the next hinted chunk if the hints are holding
             // (this chunk was one), the chunk behind this one if not (runs of opened chunks are the rule
