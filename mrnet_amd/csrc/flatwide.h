@@ -6,20 +6,29 @@
 // grid) and, at the very end, its integer S.  So the packets are cut into chunks of 1,024, and a
 // first pass guesses every chunk's exponent from an ordinary (inexact, parallel) prefix sum of the
 // wave -- the exact chain cannot be far from it -- and works out, for the guess and its two
-// neighbours, what the chunk does to ANY sum of that exponent:
-//     step[p]   the chunk's total step on S, for a sum of parity p in front of it
-//     lo[p], hi[p]   the least and the greatest exact partial sum inside the chunk, relative to S
-// (a chunk's packets are parity maps; their composition and the running offsets come out of one
-// workgroup scan per candidate exponent).  The last pass is one workgroup walking the chunks in
-// order: if the sum's exponent is one of the chunk's candidates and S + lo[p] .. S + hi[p] stays inside
-// the binade, the whole chunk is S += step[p]; otherwise (the first chunk, a chunk in which the sum
-// changes its binade, non-finite values, a bad guess) its 1,024 packets are added the plain way.
-// The exact sum is the chain's for every input: a chunk is only ever skipped under the same
-// conditions under which flatscan.h's rounds accept packets, checked against the actual S.
+// neighbours, what the chunk does to ANY sum of that exponent, of either parity p:
+//     step   the chunk's total step on S
+//     lo, hi the least and the greatest exact partial sum inside the chunk, relative to S
+// (a chunk's packets are parity maps; their composition and the running offsets come out of a
+// wavefront scan per candidate exponent).  Such summaries compose like the maps themselves
+// (wide_then), which is used twice: a chunk's summary is put together from those of its four
+// wavefronts (sub-chunks of 256 packets, kept as well), and the walk puts the summaries of up to 64
+// chunks together to step over all of them at once.
+// The last pass is one workgroup walking the chunks in order: if the sum's exponent is one of the
+// chunk's candidates and S + lo .. S + hi stays inside the binade, the whole chunk is S += step;
+// otherwise (the first chunk, a chunk in which the sum changes its binade, non-finite values, a bad
+// guess) the chunk is opened and gone through sub-chunk by sub-chunk, each in one step where its own
+// summary allows and packet by packet where not.  The exact sum is the chain's for every input: packets
+// are only ever skipped under the same conditions under which flatscan.h's rounds accept packets,
+// checked against the actual S.  The walk is one wavefront's chain of dependent instructions (an
+// instruction every ~3.8 ns): everything about it is arranged to keep that chain short -- one trip to
+// LDS per chunk, chunks that will probably be opened marked by the second pass and loaded ahead of
+// time, loading and staging left to the other wavefronts.
 //
-// Integer range: while a chunk's test holds for the actual S, every partial step inside it is
-// within 2^(MANT+2) of S, so nothing wraps; where a partial step wraps, an earlier packet of the
-// same chunk has already pushed lo / hi out of every binade, and min / max keep that.
+// Integer range: every packet's step is below 2^(MANT+2) in size, so a running sum cannot pass from
+// inside a binade to beyond the integer range without a partial sum landing in between, where it fails
+// the test for every S; lo / hi keep that (min / max) and are clamped to +-2^(MANT+3) wherever they
+// are produced, so that adding S or a step in front of them never wraps.
 #pragma once
 
 #include "flatscan.h"
