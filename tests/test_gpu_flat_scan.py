@@ -148,3 +148,31 @@ def test_scan_on_the_wire_with_both_byte_orders(codec):
     got = W.result_value(*codec.filter_wire(O.AVG, W.Format("%f %d"), wire, W.BIGENDIAN), np.dtype(np.float32), O.AVG)
     ref = O.filter_flat(O.AVG, O.FLOAT_T, vals, cnt)
     assert same_bits(got[0], ref[0]) and got[1] == ref[1]
+
+
+@pytest.mark.parametrize("t,dt", [(O.FLOAT_T, np.float32), (O.DOUBLE_T, np.float64)])
+@pytest.mark.parametrize("n", [12000, 70001])
+def test_scan_over_packets_of_both_byte_orders(codec, t, dt, n):
+    """A wave collected from senders of both byte orders, every packet read with its own
+    (src/Packet.C:118): '%f %d' / '%lf %d' rows, tfilter_Avg and tfilter_Sum of one reference call."""
+    dt = np.dtype(dt)
+    w = dt.itemsize
+    for kind in ("positive", "mixed_sign", "excursion"):
+        vals = datasets(dt, n, 77 + n)[kind]
+        cnt = (splitmix64(5 + n, n) % np.uint64(4) + np.uint64(1)).astype(np.int32)
+        orders = (splitmix64(9 + n, n) % np.uint64(3) == 0).astype(np.uint8)
+        rows = np.zeros((n, w + 4), np.uint8)
+        vb, cb = vals.view(np.uint8).reshape(n, w), cnt.view(np.uint8).reshape(n, 4)
+        rows[:, :w] = np.where(orders[:, None] != 0, vb[:, ::-1], vb)
+        rows[:, w:] = np.where(orders[:, None] != 0, cb[:, ::-1], cb)
+        dev, dord = codec.to_device(rows.reshape(-1)), codec.to_device(orders)
+        for op in (O.AVG, O.SUM):
+            res, ok = codec.filter_raw(op, t, dev.data_ptr(), w + 4, (dev.data_ptr() + w) if op == O.AVG else None, w + 4, n,
+                                       dord, W.SHAPE_FLAT)
+            torch.cuda.synchronize()
+            got = W.result_value(res, ok, dt, op)
+            with np.errstate(all="ignore"):
+                ref = O.filter_flat(op, t, vals, cnt if op == O.AVG else None)
+            assert same_value(got[0], ref[0]), (kind, n, op, got, ref)
+            if op == O.AVG:
+                assert got[1] == ref[1]
