@@ -512,17 +512,21 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
     typedef typename G::S S;
     constexpr uint32_t SUB_DW = (uint32_t)(sizeof(WideSum<S>) * WIDE_K * WIDE_SUBS / 4);     // a chunk's sub-chunk summaries, in 32-bit words
     static_assert(SUB_DW <= WIDE_TPB && WIDE_STAGE <= WIDE_TPB && WIDE_STAGE == 128, "one word / one head per thread, two 64-bit hint masks");
-    __shared__ __align__(16) T s_val[WIDE_CHUNK + 64];          // (slack: the plain fold reads a batch ahead)
+    // Two of everything an opened chunk needs: while one wavefront adds up the chunk in one set, the
+    // others may already stage the next chunk into the other.
+    __shared__ __align__(16) T s_val[2][WIDE_CHUNK + 64];       // (slack: the plain fold reads a batch ahead)
     __shared__ WideHead s_head[WIDE_STAGE];
     __shared__ WideSum<S> s_map[WIDE_STAGE * WIDE_K];
-    __shared__ __align__(16) WideSum<S> s_sub[WIDE_K * WIDE_SUBS];
+    __shared__ __align__(16) WideSum<S> s_sub[2][WIDE_K * WIDE_SUBS];
     __shared__ uint64_t s_hint[WIDE_STAGE / 64];
-    __shared__ T s_acc;
+    __shared__ T s_acc[2];
     __shared__ int32_t s_cnt;
     WideWs<T> ws(ws_base, nc);
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     if (t == 0) s_cnt = 0;
     T acc = (T)0;                                               // the same in every lane
+    uint32_t cur = 0;                                           // the set the chunk being added is in
+    uint64_t staged_of = ~(uint64_t)0;                          // the chunk already staged in the other set
 #ifdef WIDE_DEBUG
     uint32_t nplain = 0, nmiss = 0;
 #endif
@@ -579,22 +583,40 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
             nplain++;
             if (ahead_of != cc) nmiss++;
 #endif
-            if (ahead_of != cc) WIDE_FETCH(cc);
-            __syncthreads();
-#pragma unroll
-            for (uint32_t k = 0; k < LEPL; k++) {
-                const uint32_t at = k * LOADERS + u;
-                if (wave != 0 && at < WIDE_CHUNK) s_val[at] = wide_value_of<OP, T>(in, ahead[k]);
+            // Into LDS, unless it was staged while the chunk before was being added (ordered by the
+            // barrier behind that chunk).  No barrier in front of the staging: the set written here was
+            // last read two opened chunks ago, in front of the barrier that closed that chunk.
+#define WIDE_STAGE_AHEAD(set_) do { \
+        if (wave != 0) { \
+            _Pragma("unroll") for (uint32_t k = 0; k < LEPL; k++) { \
+                const uint32_t at = k * LOADERS + u; \
+                if (at < WIDE_CHUNK) s_val[set_][at] = wide_value_of<OP, T>(in, ahead[k]); \
+            } \
+            if (u < SUB_DW) ((uint32_t *)s_sub[set_])[u] = sub_ahead; \
+        } \
+    } while (0)
+            cur ^= 1u;
+            if (staged_of != cc) {
+                if (ahead_of != cc) WIDE_FETCH(cc);
+                WIDE_STAGE_AHEAD(cur);
+                __syncthreads();
             }
-            if (wave != 0 && u < SUB_DW) ((uint32_t *)s_sub)[u] = sub_ahead;
-            __syncthreads();
+            staged_of = ~(uint64_t)0;
             // What to load next, before the adding starts: the next hinted chunk if the hints are holding
             // (this chunk was one), the chunk behind this one if not (runs of opened chunks are the rule
-            // where the rough sums mislead).
+            // where the rough sums mislead).  The chunk right behind this one is staged as well, under the
+            // additions of this one: in a run of opened chunks the adding wavefront goes from chunk to
+            // chunk with one barrier in between.
             {
                 uint32_t nx = j + 1;
                 if (head.bad & WIDE_HINT) nx = wide_next_hint(hint0, hint1, j + 1, m);
-                if (nx < m) WIDE_FETCH(c0 + nx);
+                if (nx < m) {
+                    WIDE_FETCH(c0 + nx);
+                    if (nx == j + 1) {
+                        WIDE_STAGE_AHEAD(cur ^ 1u);
+                        staged_of = c0 + nx;
+                    }
+                }
             }
             if (wave == 0) {
                 // (values behind len are staged but not added)
@@ -602,19 +624,20 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
                 // had none that went in one step (data that jumps between binades from packet to packet),
                 // the next ones are added whole, and every eighth tries again.
                 const bool hopeless = (head.bad & WIDE_SUB_BITS) == WIDE_SUB_BITS;     // every sub-chunk crossed out for every candidate
-                if (hopeless || (dry >= 2 && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val, len);
+                if (hopeless || (dry >= 2 && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val[cur], len);
                 else {
                     uint32_t taken = 0;
-                    acc = wide_open<T>(acc, head, s_sub, s_val, len, taken);
+                    acc = wide_open<T>(acc, head, s_sub[cur], s_val[cur], len, taken);
                     dry = taken ? 0 : dry + 1;
                 }
-                if (lane == 0) s_acc = acc;
+                if (lane == 0) s_acc[cur] = acc;
             }
             __syncthreads();
-            acc = s_acc;
+            acc = s_acc[cur];                                   // (two of these as well: the next write of this one is two barriers away)
         }
     }
 #undef WIDE_FETCH
+#undef WIDE_STAGE_AHEAD
 #ifdef WIDE_DEBUG
     if (t == 0) printf("wide walk: %u of %llu chunks opened, %u of them not loaded ahead\n", nplain, (unsigned long long)nc, nmiss);
 #endif
