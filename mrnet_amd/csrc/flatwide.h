@@ -40,6 +40,8 @@
 #define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
+#define WIDE_LOOK 92u                   // additions that looking at one sub-chunk's summaries costs (0.35 us at 3.8 ns)
+#define WIDE_OWES 400                   // the balance below which opened chunks are added whole
 #define WIDE_MANY_MIN 4u                // chunks the hints promise in a row from which the walk takes them many at a time
 
 #define WIDE_SUBS (WIDE_TPB / 64)        // a wavefront's packets (256) are a sub-chunk with summaries of its own
@@ -472,9 +474,9 @@ template <typename T> __device__ __forceinline__ uint32_t wide_take_many(T &acc,
 // A chunk the walk could not take in one step (one wavefront; the chunk's packets in s_val, its
 // sub-chunk summaries in s_sub): sub-chunk by sub-chunk, each in one step where its test holds for the
 // sum in front of it, the plain way otherwise.  Sub-chunks that no sum can take in one step (every
-// candidate crossed out) are added in one go with their neighbours.  `taken` counts the sub-chunks
-// that went in one step.
-template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len, uint32_t &taken)
+// candidate crossed out) are added in one go with their neighbours.  `tried` counts the sub-chunks
+// whose summaries were looked at, `taken` those of them that went in one step.
+template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len, uint32_t &taken, uint32_t &tried)
 {
     uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate
 #pragma unroll
@@ -483,6 +485,7 @@ template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHe
     while (w * 64u * WIDE_EPL < len) {
         const uint32_t at = w * 64u * WIDE_EPL;
         if (!((forced >> w) & 1u) && len - at >= 64u * WIDE_EPL) {
+            tried++;
             if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; taken++; continue; }
             acc = plain_fold<T>(acc, s_val + at, 64u * WIDE_EPL);
             w++;
@@ -518,7 +521,7 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
     __shared__ WideHead s_head[WIDE_STAGE];
     __shared__ WideSum<S> s_map[WIDE_STAGE * WIDE_K];
     __shared__ __align__(16) WideSum<S> s_sub[2][WIDE_K * WIDE_SUBS];
-    __shared__ uint64_t s_hint[WIDE_STAGE / 64];
+    __shared__ uint64_t s_hint[WIDE_STAGE / 64], s_dead[WIDE_STAGE / 64];
     __shared__ T s_acc[2];
     __shared__ int32_t s_cnt;
     WideWs<T> ws(ws_base, nc);
@@ -538,7 +541,8 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
     static_assert(SUB_DW <= LOADERS, "one word of the sub-chunk summaries per loading thread");
     const uint32_t u = t - 64u;                                 // (loading threads: 0 .. LOADERS - 1)
     WideRaw<T> ahead[LEPL];
-    uint32_t dry = 0, skipped = 0;                              // (wavefront 0's: opened chunks in a row without a sub-chunk taken in one step)
+    int32_t balance = 0;                                        // (wavefront 0's: what looking at sub-chunk summaries has saved, in additions)
+    uint32_t skipped = 0;
     uint32_t sub_ahead = 0;
     uint64_t ahead_of = ~(uint64_t)0;
 #define WIDE_FETCH(cc_) do { \
@@ -559,17 +563,21 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
         for (uint32_t j = t; j < m; j += WIDE_TPB) s_head[j] = ws.heads[c0 + j];
         for (uint32_t j = t; j < m * WIDE_K; j += WIDE_TPB) s_map[j] = ws.maps[c0 * WIDE_K + j];
         if (t < WIDE_STAGE) {
-            const uint64_t b = __ballot(t < m && (ws.heads[c0 + (t < m ? t : 0)].bad & WIDE_HINT) != 0);
-            if (lane == 0) s_hint[wave] = b;
+            const uint32_t bad = ws.heads[c0 + (t < m ? t : 0)].bad;
+            const uint64_t b = __ballot(t < m && (bad & WIDE_HINT) != 0);
+            const uint64_t d = __ballot(t < m && (bad & WIDE_CHUNK_BITS) == WIDE_CHUNK_BITS);
+            if (lane == 0) { s_hint[wave] = b; s_dead[wave] = d; }
         }
         __syncthreads();
         const uint64_t hint0 = s_hint[0], hint1 = s_hint[1];
+        const uint64_t dead0 = s_dead[0], dead1 = s_dead[1];       // chunks without a summary for any exponent: not worth a look
         uint32_t calm = wide_next_hint(hint0, hint1, 0u, m);       // the next chunk that is likely to be opened
         if (calm < m && ahead_of != c0 + calm) WIDE_FETCH(c0 + calm);
         for (uint32_t j = 0; j < m; j++) {
             // (uniform: acc is the same in every lane)
             if (j > calm) calm = wide_next_hint(hint0, hint1, j, m);
-            if (calm > j && calm - j >= WIDE_MANY_MIN) {
+            if (((j < 64u ? dead0 >> j : dead1 >> (j - 64u)) & 1u) != 0) { }        // (straight to the opening)
+            else if (calm > j && calm - j >= WIDE_MANY_MIN) {
                 const uint32_t took = wide_take_many<T>(acc, &s_map[j * WIDE_K], m - j, lane);
                 j += took;
                 if (took == 64u || j >= m) { j--; continue; }
@@ -620,15 +628,17 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
             }
             if (wave == 0) {
                 // (values behind len are staged but not added)
-                // Trying the sub-chunks costs about a third of adding them: where the last chunks opened
-                // had none that went in one step (data that jumps between binades from packet to packet),
-                // the next ones are added whole, and every eighth tries again.
+                // Looking at a sub-chunk's summaries costs what some 90 additions cost, and saves 256 if
+                // the sub-chunk goes in one step.  The walk keeps a balance of that, in additions: while it
+                // is clearly negative (a sum that changes its binade every few hundred packets), opened
+                // chunks are added whole, and every eighth tries again.
                 const bool hopeless = (head.bad & WIDE_SUB_BITS) == WIDE_SUB_BITS;     // every sub-chunk crossed out for every candidate
-                if (hopeless || (dry >= 2 && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val[cur], len);
+                if (hopeless || (balance < -WIDE_OWES && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val[cur], len);
                 else {
-                    uint32_t taken = 0;
-                    acc = wide_open<T>(acc, head, s_sub[cur], s_val[cur], len, taken);
-                    dry = taken ? 0 : dry + 1;
+                    uint32_t taken = 0, tried = 0;
+                    acc = wide_open<T>(acc, head, s_sub[cur], s_val[cur], len, taken, tried);
+                    balance += (int32_t)(taken * 64u * WIDE_EPL) - (int32_t)(tried * WIDE_LOOK);
+                    balance = balance > 2048 ? 2048 : (balance < -2048 ? -2048 : balance);
                 }
                 if (lane == 0) s_acc[cur] = acc;
             }
