@@ -40,8 +40,14 @@
 #define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
-#define WIDE_LOOK 92u                   // additions that looking at one sub-chunk's summaries costs (0.35 us at 3.8 ns)
+#ifndef WIDE_LOOK
+#define WIDE_LOOK 48u                   // additions that looking at one sub-chunk's summaries is priced at
+#endif
+#ifndef WIDE_OWES
 #define WIDE_OWES 400                   // the balance below which opened chunks are added whole
+#endif
+// (measured on ten zero-mean draws and the hostile kinds: 24 / 48 / 92 and no giving up at all end
+// within 3 % of one another on the draws; 48 and 92 are 9 % ahead on data that never pays)
 #define WIDE_MANY_MIN 4u                // chunks the hints promise in a row from which the walk takes them many at a time
 
 #define WIDE_SUBS (WIDE_TPB / 64)        // a wavefront's packets (256) are a sub-chunk with summaries of its own
