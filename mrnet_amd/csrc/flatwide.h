@@ -372,6 +372,17 @@ template <typename T> __device__ __forceinline__ T wide_number(int e, typename G
                                    (sum < 0 ? (U)1 << (sizeof(U) * 8 - 1) : (U)0)));
 }
 
+// lane l's value, l the same in every lane: the answer is known to be the same in every lane too
+// (a shuffle's is not, and everything computed from it -- the sum, the walk's branches -- would be
+// carried out per lane)
+__device__ __forceinline__ int32_t wide_of_lane(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
+__device__ __forceinline__ int64_t wide_of_lane(int64_t v, uint32_t l)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, (int)l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), (int)l);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // one side out of LDS, in 128-bit reads
 __device__ __forceinline__ WideSide<int32_t> wide_side(const WideSide<int32_t> *p)
 {
@@ -392,8 +403,8 @@ __device__ __forceinline__ WideSide<int64_t> wide_side(const WideSide<int64_t> *
 
 // The three candidates' summaries of one run of packets (w, w + stride, w + 2 * stride) against the
 // actual sum: if one of them is for acc's exponent and every exact partial sum stays inside acc's
-// binade, acc takes the whole step and the answer is true.  All three are read at once, before it is
-// known which one counts: one trip to LDS on the chain from sum to sum.
+// binade, acc takes the whole step and the answer is true.  All three are read at once (a lane each),
+// before it is known which one counts: one trip to LDS on the chain from sum to sum.
 template <typename T> __device__ __forceinline__ bool wide_take(T &acc, const WideSum<typename Grid<T>::S> *w, uint32_t stride)
 {
     typedef Grid<T> G;
@@ -406,24 +417,17 @@ template <typename T> __device__ __forceinline__ bool wide_take(T &acc, const Wi
     const U afrac = (ab & (((U)1 << G::MANT) - 1)) | ((U)1 << G::MANT);
     const S s0 = (ab >> (sizeof(U) * 8 - 1)) ? -(S)afrac : (S)afrac;
     const int p = (int)(s0 & 1);
-    const WideSide<S> c0 = wide_side(&w[0].of[p]), c1 = wide_side(&w[stride].of[p]), c2 = wide_side(&w[2 * stride].of[p]);
-    const bool i0 = c0.e == (S)e, i1 = c1.e == (S)e, i2 = c2.e == (S)e;
-    if (!(i0 || i1 || i2)) return false;
-    const S lo = i0 ? c0.lo : (i1 ? c1.lo : c2.lo), hi = i0 ? c0.hi : (i1 ? c1.hi : c2.hi), step = i0 ? c0.step : (i1 ? c1.step : c2.step);
+    // lane k reads candidate k (the lanes from WIDE_K on read the last one again); the lane whose side
+    // is for acc's exponent hands it to everybody
+    const uint32_t k = threadIdx.x & 63u;
+    const WideSide<S> c = wide_side(&w[(k < WIDE_K ? k : WIDE_K - 1u) * stride].of[p]);
+    const uint64_t is = __ballot(c.e == (S)e);
+    if (!is) return false;
+    const uint32_t from = (uint32_t)__ffsll((unsigned long long)is) - 1u;
+    const S lo = wide_of_lane(c.lo, from), hi = wide_of_lane(c.hi, from), step = wide_of_lane(c.step, from);
     if (!wide_inside<T>(s0 + lo, s0 + hi, (S)0)) return false;
     acc = wide_number<T>(e, s0 + step);
     return true;
-}
-
-// lane l's value, l the same in every lane: the answer is known to be the same in every lane too
-// (a shuffle's is not, and everything computed from it -- the sum, the walk's branches -- would be
-// carried out per lane)
-__device__ __forceinline__ int32_t wide_of_lane(int32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, (int)l); }
-__device__ __forceinline__ int64_t wide_of_lane(int64_t v, uint32_t l)
-{
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(uint64_t)v, (int)l);
-    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), (int)l);
-    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // A run of chunks at once (w: the first one's summaries, WIDE_K per chunk; avail: how many there are):
