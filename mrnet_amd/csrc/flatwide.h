@@ -510,6 +510,13 @@ template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHe
     return acc;
 }
 
+// a value that is the same in every lane, said so
+__device__ __forceinline__ uint64_t wide_uniform(uint64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 // the first hinted chunk of a stage (a bit per chunk in h0, h1) at or behind `from`; m if there is none
 __device__ __forceinline__ uint32_t wide_next_hint(uint64_t h0, uint64_t h1, uint32_t from, uint32_t m)
 {
@@ -579,8 +586,9 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
             if (lane == 0) { s_hint[wave] = b; s_dead[wave] = d; }
         }
         __syncthreads();
-        const uint64_t hint0 = s_hint[0], hint1 = s_hint[1];
-        const uint64_t dead0 = s_dead[0], dead1 = s_dead[1];       // chunks without a summary for any exponent: not worth a look
+        // (kept in scalar registers: the walk tests a bit of these per chunk)
+        const uint64_t hint0 = wide_uniform(s_hint[0]), hint1 = wide_uniform(s_hint[1]);
+        const uint64_t dead0 = wide_uniform(s_dead[0]), dead1 = wide_uniform(s_dead[1]);       // chunks without a summary for any exponent: not worth a look
         uint32_t calm = wide_next_hint(hint0, hint1, 0u, m);       // the next chunk that is likely to be opened
         if (calm < m && ahead_of != c0 + calm) WIDE_FETCH(c0 + calm);
         for (uint32_t j = 0; j < m; j++) {
