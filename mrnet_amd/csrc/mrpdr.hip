@@ -1218,10 +1218,14 @@ static int32_t run_tree(const FilterWs &fw, const FilterIn &in, uint8_t *result,
 // Below this many packets the scan's rounds do not pay (measured, growing sums: 4,096 floats 22 us
 // against the plain chain's 17, 8,192: 31 against 33, 16,383: 44 against 64).
 #define FLAT_SCAN_MIN 8192
-// From here on three launches over the whole device beat the one workgroup.
+// From here on three launches over the whole device beat the one workgroup.  For doubles, whose
+// rounds cost the one workgroup more, already from 8,192 (measured on growing sums: 33 against 42 us
+// there, 45 against 63 at 16,383; floats 28 against 31 and 38 against 44, which is within what data
+// that opens every chunk loses: 5-8 us).
 #ifndef FLAT_WIDE_MIN
 #define FLAT_WIDE_MIN 16384
 #endif
+#define FLAT_WIDE_MIN_DOUBLE 8192
 
 template <int OP, typename T>
 static int32_t run_flat(const FilterWs &fw, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st,
@@ -1229,7 +1233,7 @@ static int32_t run_flat(const FilterWs &fw, const FilterIn &in, uint8_t *result,
 {
     constexpr bool fp = std::is_floating_point<T>::value;
     if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
-        if (!serial && in.n >= FLAT_WIDE_MIN && fw.wide) {
+        if (!serial && in.n >= (sizeof(T) == 8 ? FLAT_WIDE_MIN_DOUBLE : FLAT_WIDE_MIN) && fw.wide) {
             // large waves: the per-packet work on the whole device, one workgroup walks the chunks
             const uint64_t nc = (in.n + WIDE_CHUNK - 1) / WIDE_CHUNK;
             if (WideWs<T>::bytes(nc) <= fw.wide_bytes) {

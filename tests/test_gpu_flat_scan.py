@@ -1,6 +1,6 @@
 """One reference filter call over float / double waves (tfilter_Sum, tfilter_Avg: every addition
 rounds, src/FilterDefinitions.C:148, 1955-1960) computed by the binade-at-a-time scan (one workgroup
-from 8,192 up to 16,383 packets, chunk summaries over the whole device from 16,384 on) against the
+from 8,192 up to 16,383 floats, chunk summaries over the whole device from 16,384 floats / 8,192 doubles on) against the
 plain chain of additions on the device (MRPDR_SHAPE_FLAT_SERIAL) and against the oracle's loop on the
 CPU: the same bits on data chosen to break the scan -- ties at every step, sums hovering around a
 power of two, cancellation, forty binades of dynamic range, zeros, subnormals, infinities, NaNs and
