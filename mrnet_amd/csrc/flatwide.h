@@ -48,7 +48,10 @@
 #endif
 // (measured on ten zero-mean draws and the hostile kinds: 24 / 48 / 92 and no giving up at all end
 // within 3 % of one another on the draws; 48 and 92 are 9 % ahead on data that never pays)
+#ifndef WIDE_MANY_MIN
 #define WIDE_MANY_MIN 4u                // chunks the hints promise in a row from which the walk takes them many at a time
+#endif
+// (2, 3, 4 and 6 measured within 1 % of one another)
 
 #define WIDE_SUBS (WIDE_TPB / 64)        // a wavefront's packets (256) are a sub-chunk with summaries of its own
 static_assert(WIDE_TPB * WIDE_EPL == WIDE_CHUNK && 4 + WIDE_K * WIDE_SUBS <= 31, "head.bad holds a bit per candidate and sub-chunk");
