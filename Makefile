@@ -8,9 +8,10 @@ LIB      = mrnet_amd/lib/libmrpdr.so
 HOSTTEST = tests/host/test_packet_wave
 CTEST    = tests/host/test_c_abi
 PLUGTEST = tests/host/test_plugin
+RCCLTEST = tests/host/test_rccl_combine
 ROCM    ?= /opt/rocm
 
-all: $(LIB) oracle $(HOSTTEST) $(CTEST) plugin-check $(PLUGTEST)
+all: $(LIB) oracle $(HOSTTEST) $(CTEST) plugin-check $(PLUGTEST) $(RCCLTEST)
 
 $(LIB): $(SRC)/mrpdr.hip $(wildcard $(SRC)/*.h) include/mrpdr.h
 	mkdir -p mrnet_amd/lib
@@ -35,6 +36,11 @@ $(PLUGTEST): tests/host/test_plugin.cpp integration/mrpdr_filters.C integration/
 		tests/host/test_plugin.cpp -Lmrnet_amd/lib -lmrpdr -L$(ROCM)/lib -lamdhip64 \
 		-Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib' -Wl,-rpath,$(ROCM)/lib
 
+# One filter call over a wave held by several GPUs, from C++: RCCL for the exchange of the 16-byte nodes
+$(RCCLTEST): tests/host/test_rccl_combine.cpp include/mrpdr.h $(LIB)
+	$(HIPCC) -O2 -std=c++17 -Wall -ffp-contract=off -o $@ tests/host/test_rccl_combine.cpp -Lmrnet_amd/lib -lmrpdr \
+		-L$(ROCM)/lib -lrccl -lpthread -Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib' -Wl,-rpath,$(ROCM)/lib
+
 # The MRNet filter plugin compiles (objects only: it links against a real MRNet tree, which is not
 # here).  integration/buildcheck/ holds a stand-in for the few MRNet declarations it uses.
 plugin-check: integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h include/mrpdr.h
@@ -42,7 +48,7 @@ plugin-check: integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h i
 		-I$(ROCM)/include integration/mrpdr_filters.C
 
 clean:
-	rm -f $(LIB) $(HOSTTEST) $(CTEST) $(PLUGTEST)
+	rm -f $(LIB) $(HOSTTEST) $(CTEST) $(PLUGTEST) $(RCCLTEST)
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean plugin-check

@@ -315,10 +315,13 @@ def small_wave_extras(codec):
         flag = rok_h.numpy()
 
         def call_poll():
-            flag[0] = 0
+            flag[0] = -1                     # MRPDR_RESULT_PENDING: 0 and 1 are both final values
             call_h()
-            while flag[0] == 0:
-                pass
+            spins = 0
+            while flag[0] == -1:
+                spins += 1
+                if spins > 200_000_000:
+                    raise RuntimeError("the polled result never arrived")
         sweep[str(ns)] = {"streamed": round(time_call(call, 300) * 1e6, 2),
                           "host_waits": round(time_call(call_wait, 300) * 1e6, 2),
                           "host_polls_pinned_result": round(time_call(call_poll, 300) * 1e6, 2)}

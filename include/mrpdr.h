@@ -409,7 +409,14 @@ int32_t mrpdr_wave_view(const mrpdr_fmt *f, const char *fmt_expected, const mrpd
  *   values = wire.base, value_stride = packet stride, counts = wire.base + sizeof(T).
  * result (device, 16 bytes): the data bytes of the output packet the reference filter
  * would build -- T value, then for AVG the int32 count -- in native order, zero padded.
- * result_ok (device int32, optional): 0 when n == 0 or an AVG count sum was zero. */
+ * result_ok (device int32, optional): 1 = result present, 0 = absent (n == 0, or an AVG whose
+ * counts sum to zero: the reference emits no packet).
+ * result and result_ok may point into pinned host memory.  The sixteen result bytes are written
+ * first, then a system-scope fence, then result_ok with release semantics: a host thread that
+ * polls instead of synchronising presets *result_ok to MRPDR_RESULT_PENDING, waits until it reads
+ * 0 or 1 (an acquire load), and then finds the result bytes complete.  (0 is a final value --
+ * "absent" -- so it cannot serve as the pending mark.) */
+#define MRPDR_RESULT_PENDING (-1)
 int32_t mrpdr_wave_filter(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_t shape,
                           const void *values, uint64_t value_stride,
                           const void *counts, uint64_t count_stride,
@@ -425,6 +432,54 @@ int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *ctx, int32_t op, int32_t type, int32_
                                 const void *counts, uint64_t count_stride,
                                 uint64_t n, const uint8_t *byteorders,
                                 void *result, int32_t *result_ok, void *stream);
+
+/* ---- one filter call over a wave that is held in ranges ---------------------------------
+ * In the reference a node's wave goes through ONE tfilter_* call, however many packets it has
+ * (Filter::push_Packets hands the whole vector to the filter function, src/Filter.C:42-117;
+ * tfilter_Avg multiplies, sums and divides once, src/FilterDefinitions.C:517-561).  When the packets
+ * of that wave lie on several GPUs (contiguous packet ranges, rank order), every GPU reduces its own
+ * range to a 16-byte NODE, the nodes are exchanged, and combining them in range order gives the
+ * result of that one call -- the same bits as MRPDR_SHAPE_FLAT over the whole wave.  The GPUs are not
+ * tree levels: nothing is divided or rounded per range that the one call would not divide or round.
+ *
+ * What a node holds (native order):
+ *   integer SUM / MIN / MAX / OR / AND   bits = the range's result
+ *   integer AVG                          bits = sum of (T)(value * count), wrapping, in T;
+ *                                        count = sum of the counts (the ONE division is the combine's)
+ *   float / double MIN / MAX             bits = the range's result, count = 1 when a NaN restarted the
+ *                                        comparison inside the range ((r > x) ? r : x keeps the new
+ *                                        element whenever the comparison is false)
+ *   float / double SUM / AVG             bits = the running sum of the chain of additions (AVG: of
+ *                                        value * count, count = sum of the counts, undivided)
+ *   present = 0: no packet below this node.
+ * Every addition of a float or double SUM / AVG rounds, so that chain has to be CONTINUED, not
+ * re-associated: mrpdr_filter_is_chained(op, type) says so, and for those the ranges are taken one
+ * after the other, range r + 1 with `front` = the node range r left (a relay in rank order; the last
+ * node is the wave's).  Every other (op, type) needs no order between the calls: front = NULL
+ * everywhere, one all-gather of the nodes, one combine.  (`front` is honoured for those too: the node
+ * then covers front + range.)
+ *
+ * mrpdr_wave_filter_partial: arguments as mrpdr_wave_filter; front (device, may be NULL) = node of
+ * the packets in front of this range; node (device) receives the node of front + range.  n = 0 is
+ * allowed (a rank without packets hands `front` on).
+ * mrpdr_wave_filter_combine: nodes = g nodes in range order (device).  Chained operators take the
+ * LAST node (it holds the whole chain when the ranges were relayed as above); all others fold the g
+ * nodes in order.  result / result_ok as mrpdr_wave_filter. */
+typedef struct mrpdr_node {
+    uint64_t bits;
+    int32_t  count;
+    int32_t  present;
+} mrpdr_node;
+
+int32_t mrpdr_filter_is_chained(int32_t op, int32_t type);
+int32_t mrpdr_wave_filter_partial(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                  const void *values, uint64_t value_stride,
+                                  const void *counts, uint64_t count_stride,
+                                  uint64_t n, int32_t swap,
+                                  const mrpdr_node *front, mrpdr_node *node, void *stream);
+int32_t mrpdr_wave_filter_combine(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                  const mrpdr_node *nodes, uint64_t g,
+                                  void *result, int32_t *result_ok, void *stream);
 
 /* What a tree node does with an upstream wave, in one call: decode the packets
  * (Packet::decode_pdr_data, src/Packet.C:106-133, triggered by the filter's (*pkt)[0],

@@ -182,15 +182,46 @@ __device__ inline int32_t load_count(const FilterIn &in, uint64_t i)
 
 // The data bytes of the filter's output packet: T value [, int32 count], no padding
 // between them (Packet::pdr_packet_data ENCODE of "%T" or "%T %d").
+// result and result_ok may lie in host memory that a node thread polls instead of synchronising
+// (it presets *result_ok to a value that is neither 0 nor 1 and waits for it to change): the flag is
+// therefore stored last, behind a system-scope fence, with release semantics -- whoever sees the
+// flag sees the sixteen result bytes.
 template <int OP, typename T>
 __device__ inline void write_result(uint8_t *result, int32_t *result_ok, bool present, T v, int32_t cnt)
 {
-    for (int b = 0; b < 16; b++) result[b] = 0;
+    uint64_t lo = 0, hi = 0;
     if (present) {
-        st_u<T>(result, v);
-        if (OpTraits<OP>::pair_result) st_u<int32_t>(result + sizeof(T), cnt);
+        uint8_t b[16] = { 0 };
+        __builtin_memcpy(b, &v, sizeof(T));
+        if (OpTraits<OP>::pair_result) __builtin_memcpy(b + sizeof(T), &cnt, 4);
+        __builtin_memcpy(&lo, b, 8);
+        __builtin_memcpy(&hi, b + 8, 8);
     }
-    if (result_ok) *result_ok = present ? 1 : 0;
+    st_u<uint64_t>(result, lo);
+    st_u<uint64_t>(result + 8, hi);
+    if (result_ok) {
+        __threadfence_system();
+        __hip_atomic_store(result_ok, present ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// A filter call over a RANGE of a wave's packets (the wave is spread over several GPUs, or comes in
+// pieces): `front` is the node of the packets in front of the range (NULL: the range starts the
+// wave), and the call leaves in `node` the node of front + range instead of a result.  What a node
+// holds depends on how the operator's single reference call is computed (see OP_AVGSUM / OP_MINR /
+// OP_MAXR above): the value so far, for AVG the undivided sum of value * count with the summed
+// count, for float MIN / MAX the NaN mark; float and double SUM / AVG hold the running sum of the
+// chain of additions itself, which is why their ranges have to be taken in order, each from the
+// node the range before it left.
+struct FilterLink { const Partial *front; Partial *node; };
+
+template <typename T> __device__ inline void write_node(Partial *node, bool present, T v, int32_t cnt)
+{
+    Partial out;
+    out.bits = present ? to_bits<T>(v) : 0;
+    out.cnt = present ? cnt : 0;
+    out.present = present ? 1 : 0;
+    *node = out;
 }
 
 // ---- tree shape, levels 0..7: one partial per workgroup -------------------------
@@ -362,10 +393,14 @@ __device__ inline void fold_nodes(Folder<OP, T> &g, const Partial *stage, uint32
 // Contains workgroup barriers: every thread calls it.
 template <int OP, typename T>
 __device__ inline void tree_top(const Partial *partials, uint64_t np, uint8_t *result, int32_t *result_ok,
-                                Partial *stage)
+                                Partial *stage, FilterLink link = FilterLink{ nullptr, nullptr })
 {
     Folder<OP, T> g;
     g.init();
+    if (link.front && threadIdx.x == 0) {            // the packets in front of this range: the leftmost child
+        const Partial f = *link.front;
+        if (f.present) g.add(from_bits<T>(f.bits), f.cnt);
+    }
     for (uint64_t base = 0; base < np; base += FLAT_TILE) {
         const uint32_t m = (uint32_t)((np - base) < FLAT_TILE ? (np - base) : FLAT_TILE);
         __syncthreads();
@@ -378,6 +413,10 @@ __device__ inline void tree_top(const Partial *partials, uint64_t np, uint8_t *r
         if (threadIdx.x == 0) fold_nodes<OP, T>(g, stage, m, dense);
     }
     if (threadIdx.x == 0) {
+        if (link.node) {
+            write_node<T>(link.node, g.finish(), g.res, g.cnt);
+            return;
+        }
         const bool present = g.finish_top();
         write_result<OP, T>(result, result_ok, present, g.res, g.cnt);
     }
@@ -389,6 +428,44 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_top(const Partial *pa
 {
     __shared__ Partial stage[FLAT_TILE];
     tree_top<OP, T>(partials, np, result, result_ok, stage);
+}
+
+// The last level of a range's own tree, with the node in front as its leftmost child, left as a node
+// (link.node), or -- np nodes of consecutive ranges, link empty -- the filter's result.
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_tree_link(const Partial *partials, uint64_t np, FilterLink link,
+                                                                uint8_t *result, int32_t *result_ok)
+{
+    __shared__ Partial stage[FLAT_TILE];
+    tree_top<OP, T>(partials, np, result, result_ok, stage, link);
+}
+
+// ---- the chain of float / double additions, taken up and handed on ----------------------------------
+// Where the chain starts (the sum the packets in front left, 0 without any) ...
+template <typename T> __device__ inline T chain_start(const FilterLink &link)
+{
+    if (!link.front) return (T)0;
+    const Partial f = *link.front;
+    return f.present ? from_bits<T>(f.bits) : (T)0;
+}
+// ... and where it ends (one thread): the node of front + range, or the filter's result
+template <int OP, typename T>
+__device__ inline void chain_finish(const FilterLink &link, uint64_t n, T acc, int32_t cnt, uint8_t *result, int32_t *result_ok)
+{
+    bool present = n != 0;
+    if (link.front) {
+        const Partial f = *link.front;
+        if (f.present) { present = true; cnt += f.cnt; }
+    }
+    if (link.node) {
+        write_node<T>(link.node, present, acc, OP == MRPDR_AVG ? cnt : 0);
+        return;
+    }
+    if (OP == MRPDR_AVG) {
+        if (cnt == 0) present = false;
+        else acc = div_cnt<T>(acc, cnt);
+    }
+    write_result<OP, T>(result, result_ok, present, acc, cnt);
 }
 
 // ---- Min, Max and Avg of one '<T> %d' wave in one pass ------------------------------
@@ -514,14 +591,15 @@ template <typename T, bool COUNTS> struct FlatRaw {
 };
 
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t *result, int32_t *result_ok)
+__global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t *result, int32_t *result_ok,
+                                                           FilterLink link = FilterLink{ nullptr, nullptr })
 {
     __shared__ __align__(16) T sv[2][FLAT_TILE];
     __shared__ int32_t s_cnt;
     const uint32_t t = threadIdx.x;
     if (t == 0) s_cnt = 0;
     const uint64_t ntiles = (in.n + FLAT_TILE - 1) / FLAT_TILE;
-    T acc = (T)0;
+    T acc = chain_start<T>(link);
     int32_t mycnt = 0;
     FlatRaw<T, OP == MRPDR_AVG> regs;
     if (ntiles) {
@@ -567,15 +645,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_filter_flat(FilterIn in, uint8_t 
         if ((t & 63u) == 0) atomicAdd(&s_cnt, mycnt);
         __syncthreads();
     }
-    if (t == 0) {
-        const int32_t cnt = s_cnt;
-        bool present = in.n != 0;
-        if (OP == MRPDR_AVG) {
-            if (cnt == 0) present = false;
-            else acc = div_cnt<T>(acc, cnt);
-        }
-        write_result<OP, T>(result, result_ok, present, acc, cnt);
-    }
+    if (t == 0) chain_finish<OP, T>(link, in.n, acc, s_cnt, result, result_ok);
 }
 
 // ---------------------------------------------------------------------------

@@ -171,7 +171,8 @@ template <typename T> __device__ __forceinline__ T plain_fold(T acc, const T *s,
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint8_t *result, int32_t *result_ok)
+__global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint8_t *result, int32_t *result_ok,
+                                                               FilterLink link = FilterLink{ nullptr, nullptr })
 {
     typedef Grid<T> G;
     typedef typename G::U U;
@@ -188,12 +189,13 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
     __shared__ GridMap<S> s_wave[SCAN_WAVES];
     __shared__ uint32_t s_bad[SCAN_WAVES];
     __shared__ S s_sum[SCAN_WAVES];
-    __shared__ T s_acc;
+    __shared__ T s_acc[2];                              // (two, used in turn: a wavefront may still be reading one
+                                                        //  when wavefront 0, one barrier on, writes the next sum)
     __shared__ int32_t s_cnt;
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     if (t == 0) s_cnt = 0;
     // acc, pos and the back-off state are the same in every lane: every lane computes them
-    T acc = (T)0;
+    T acc = chain_start<T>(link);
     uint64_t pos = 0, wbase = 0, wend = 0;
     // length of the next plain stretch.  The first one is a full one: the sum starts at zero, and a
     // sum that grows from nothing changes its binade every few packets at first
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
     int32_t credit = 0;
     uint32_t owed = 0;
     int32_t mycnt = 0;
+    uint32_t flip = 0;
     while (pos < in.n) {
         if (pos == wend) {
             // the next window of values (times count for AVG), in arrival order.  (Its loads issued a
@@ -357,10 +360,11 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
         // (one wavefront walks the chain, the others wait: sixteen copies of it would share four SIMDs)
         if (wave == 0) {
             acc = plain_fold<T>(acc, s, run);
-            if (lane == 0) s_acc = acc;
+            if (lane == 0) s_acc[flip] = acc;
         }
         __syncthreads();
-        acc = s_acc;
+        acc = s_acc[flip];
+        flip ^= 1u;
         pos += run;
     }
     if (COUNTS) {
@@ -370,13 +374,5 @@ __global__ __launch_bounds__(SCAN_TPB) void k_filter_flat_scan(FilterIn in, uint
         if (lane == 0) atomicAdd(&s_cnt, mycnt);
         __syncthreads();
     }
-    if (t == 0) {
-        const int32_t cnt = s_cnt;
-        bool present = in.n != 0;
-        if (COUNTS) {
-            if (cnt == 0) present = false;
-            else acc = div_cnt<T>(acc, cnt);
-        }
-        write_result<OP, T>(result, result_ok, present, acc, cnt);
-    }
+    if (t == 0) chain_finish<OP, T>(link, in.n, acc, s_cnt, result, result_ok);
 }

@@ -205,7 +205,7 @@ template <typename T> __device__ __forceinline__ bool wide_inside(typename Grid<
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_base, uint64_t nc)
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_base, uint64_t nc, FilterLink link = FilterLink{ nullptr, nullptr })
 {
     typedef Grid<T> G;
     typedef typename G::S S;
@@ -225,6 +225,7 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_ba
     double a = 0;
     for (uint64_t j = t; j < c; j += WIDE_TPB) a += ws.sums[j];
     a = wide_block_sum(a, s_part);                              // (its barriers are behind s_bad = 0)
+    a += (double)chain_start<T>(link);                          // (a range of a wave: the sum the packets in front left)
     WideHead head;
     head.e0 = 0; head.bad = WIDE_ALL_BAD;
     uint64_t abits;
@@ -529,7 +530,8 @@ __device__ __forceinline__ uint32_t wide_next_hint(uint64_t h0, uint64_t h1, uin
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok)
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok,
+                                                        FilterLink link = FilterLink{ nullptr, nullptr })
 {
     typedef Grid<T> G;
     typedef typename G::S S;
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
     WideWs<T> ws(ws_base, nc);
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     if (t == 0) s_cnt = 0;
-    T acc = (T)0;                                               // the same in every lane
+    T acc = chain_start<T>(link);                               // the same in every lane
     uint32_t cur = 0;                                           // the set the chunk being added is in
     uint64_t staged_of = ~(uint64_t)0;                          // the chunk already staged in the other set
 #ifdef WIDE_DEBUG
@@ -681,13 +683,5 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
         if (lane == 0) atomicAdd(&s_cnt, cnt);
         __syncthreads();
     }
-    if (t == 0) {
-        cnt = s_cnt;
-        bool present = in.n != 0;
-        if (OP == MRPDR_AVG) {
-            if (cnt == 0) present = false;
-            else acc = div_cnt<T>(acc, cnt);
-        }
-        write_result<OP, T>(result, result_ok, present, acc, cnt);
-    }
+    if (t == 0) chain_finish<OP, T>(link, in.n, acc, s_cnt, result, result_ok);
 }

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdarg.h>
+#include <stddef.h>
 #include <type_traits>
 #include <mutex>
 
@@ -1210,6 +1211,23 @@ static int32_t run_tree(const FilterWs &fw, const FilterIn &in, uint8_t *result,
     return 1;
 }
 
+// The same over a range of a wave: the range's own tree, then its last level with the node in front as
+// leftmost child, left as a node.
+template <int OP, typename T>
+static int32_t run_tree_link(const FilterWs &fw, const FilterIn &in, FilterLink link, hipStream_t st)
+{
+    const uint32_t tiles = in.n ? blocks_for(in.n, FILTER_TILE) : 0;
+    if (tiles) {
+        k_filter_tree_tile<OP, T><<<tiles, MRPDR_TPB, 0, st>>>(in, fw.partials, nullptr, nullptr);
+        LAUNCHED("k_filter_tree_tile");
+    }
+    k_filter_tree_link<OP, T><<<1, MRPDR_TPB, 0, st>>>(fw.partials, tiles, link, nullptr, nullptr);
+    LAUNCHED("k_filter_tree_link");
+    return 1;
+}
+
+#define SHAPE_COMBINE 64      // (inside the library only: "values" are the nodes of consecutive ranges)
+
 // One reference filter call over the whole wave (MRPDR_SHAPE_FLAT).  Only SUM and AVG of float
 // and double depend on the order of the additions and take the serial kernel; every other result
 // is computed level by level with the same bits: integer SUM / MIN / MAX / OR / AND as they are,
@@ -1229,9 +1247,10 @@ static int32_t run_tree(const FilterWs &fw, const FilterIn &in, uint8_t *result,
 
 template <int OP, typename T>
 static int32_t run_flat(const FilterWs &fw, const FilterIn &in, uint8_t *result, int32_t *result_ok, hipStream_t st,
-                        bool serial = false)
+                        bool serial = false, FilterLink link = FilterLink{ nullptr, nullptr })
 {
     constexpr bool fp = std::is_floating_point<T>::value;
+    const bool ranged = link.front || link.node;      // a range of a wave (mrpdr_wave_filter_partial)
     if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
         if (!serial && in.n >= (sizeof(T) == 8 ? FLAT_WIDE_MIN_DOUBLE : FLAT_WIDE_MIN) && fw.wide) {
             // large waves: the per-packet work on the whole device, one workgroup walks the chunks
@@ -1239,56 +1258,78 @@ static int32_t run_flat(const FilterWs &fw, const FilterIn &in, uint8_t *result,
             if (WideWs<T>::bytes(nc) <= fw.wide_bytes) {
                 k_wide_sums<OP, T><<<(uint32_t)nc, WIDE_TPB, 0, st>>>(in, fw.wide, nc);
                 LAUNCHED("k_wide_sums");
-                k_wide_maps<OP, T><<<(uint32_t)nc, WIDE_TPB, 0, st>>>(in, fw.wide, nc);
+                k_wide_maps<OP, T><<<(uint32_t)nc, WIDE_TPB, 0, st>>>(in, fw.wide, nc, link);
                 LAUNCHED("k_wide_maps");
-                k_wide_walk<OP, T><<<1, WIDE_TPB, 0, st>>>(in, fw.wide, nc, result, result_ok);
+                k_wide_walk<OP, T><<<1, WIDE_TPB, 0, st>>>(in, fw.wide, nc, result, result_ok, link);
                 LAUNCHED("k_wide_walk");
                 return 1;
             }
         }
         if (!serial && in.n >= FLAT_SCAN_MIN) {
             // the same chain, taken a binade at a time by a scan (flatscan.h): same bits
-            k_filter_flat_scan<OP, T><<<1, SCAN_TPB, 0, st>>>(in, result, result_ok);
+            k_filter_flat_scan<OP, T><<<1, SCAN_TPB, 0, st>>>(in, result, result_ok, link);
             LAUNCHED("k_filter_flat_scan");
             return 1;
         }
-        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok);
+        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(in, result, result_ok, link);
         LAUNCHED("k_filter_flat");
         return 1;
     } else if constexpr (fp && OP == MRPDR_MIN) {
-        return run_tree<OP_MINR, T>(fw, in, result, result_ok, st);
+        return ranged ? run_tree_link<OP_MINR, T>(fw, in, link, st) : run_tree<OP_MINR, T>(fw, in, result, result_ok, st);
     } else if constexpr (fp && OP == MRPDR_MAX) {
-        return run_tree<OP_MAXR, T>(fw, in, result, result_ok, st);
+        return ranged ? run_tree_link<OP_MAXR, T>(fw, in, link, st) : run_tree<OP_MAXR, T>(fw, in, result, result_ok, st);
     } else if constexpr (!fp && OP == MRPDR_AVG) {
-        return run_tree<OP_AVGSUM, T>(fw, in, result, result_ok, st);
+        return ranged ? run_tree_link<OP_AVGSUM, T>(fw, in, link, st) : run_tree<OP_AVGSUM, T>(fw, in, result, result_ok, st);
     } else {
-        return run_tree<OP, T>(fw, in, result, result_ok, st);
+        return ranged ? run_tree_link<OP, T>(fw, in, link, st) : run_tree<OP, T>(fw, in, result, result_ok, st);
+    }
+}
+
+// The nodes of consecutive ranges of one wave (mrpdr_wave_filter_partial), in order, into the result
+// of the one reference call over the whole wave.
+template <int OP, typename T>
+static int32_t run_combine(const Partial *nodes, uint64_t g, uint8_t *result, int32_t *result_ok, hipStream_t st)
+{
+    constexpr bool fp = std::is_floating_point<T>::value;
+    if constexpr (fp && (OP == MRPDR_SUM || OP == MRPDR_AVG)) {
+        // the chain went through the ranges one after the other: the last node holds all of it
+        // (a fold of no packets from that node on: the division of AVG and the result's form)
+        FilterIn none = { nullptr, 0, nullptr, 0, 0, 0, nullptr };
+        k_filter_flat<OP, T><<<1, MRPDR_TPB, 0, st>>>(none, result, result_ok, FilterLink{ g ? nodes + (g - 1) : nullptr, nullptr });
+        LAUNCHED("k_filter_flat");
+        return 1;
+    } else {
+        constexpr int TOP = (fp && OP == MRPDR_MIN) ? OP_MINR : (fp && OP == MRPDR_MAX) ? OP_MAXR : (!fp && OP == MRPDR_AVG) ? OP_AVGSUM : OP;
+        k_filter_tree_link<TOP, T><<<1, MRPDR_TPB, 0, st>>>(nodes, g, FilterLink{ nullptr, nullptr }, result, result_ok);
+        LAUNCHED("k_filter_tree_link");
+        return 1;
     }
 }
 
 template <int OP, typename T>
 static int32_t run_filter(const FilterWs &fw, int32_t shape, const FilterIn &in, uint8_t *result,
-                          int32_t *result_ok, hipStream_t st)
+                          int32_t *result_ok, hipStream_t st, FilterLink link)
 {
-    if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(fw, in, result, result_ok, st);
+    if (shape == SHAPE_COMBINE) return run_combine<OP, T>((const Partial *)in.values, in.n, result, result_ok, st);
+    if (shape == MRPDR_SHAPE_FLAT) return run_flat<OP, T>(fw, in, result, result_ok, st, false, link);
     if (shape == MRPDR_SHAPE_FLAT_SERIAL) return run_flat<OP, T>(fw, in, result, result_ok, st, true);
     return run_tree<OP, T>(fw, in, result, result_ok, st);
 }
 
 template <typename T>
 static int32_t run_filter_op(const FilterWs &fw, int32_t op, int32_t shape, const FilterIn &in, uint8_t *result,
-                             int32_t *result_ok, hipStream_t st)
+                             int32_t *result_ok, hipStream_t st, FilterLink link)
 {
     switch (op) {
-    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(fw, shape, in, result, result_ok, st);
-    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(fw, shape, in, result, result_ok, st);
-    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(fw, shape, in, result, result_ok, st);
-    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(fw, shape, in, result, result_ok, st);
+    case MRPDR_SUM: return run_filter<MRPDR_SUM, T>(fw, shape, in, result, result_ok, st, link);
+    case MRPDR_MIN: return run_filter<MRPDR_MIN, T>(fw, shape, in, result, result_ok, st, link);
+    case MRPDR_MAX: return run_filter<MRPDR_MAX, T>(fw, shape, in, result, result_ok, st, link);
+    case MRPDR_AVG: return run_filter<MRPDR_AVG, T>(fw, shape, in, result, result_ok, st, link);
     case MRPDR_OR:
-        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_OR, T>(fw, shape, in, result, result_ok, st);
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_OR, T>(fw, shape, in, result, result_ok, st, link);
         break;
     case MRPDR_AND:
-        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_AND, T>(fw, shape, in, result, result_ok, st);
+        if constexpr (!std::is_floating_point<T>::value) return run_filter<MRPDR_AND, T>(fw, shape, in, result, result_ok, st, link);
         break;
     }
     return fail("mrpdr_wave_filter: unknown operator %d", op);
@@ -1299,12 +1340,13 @@ static int32_t filter_dispatch(const FilterWs &fw, int32_t op, int32_t type, int
                                const void *values, uint64_t value_stride,
                                const void *counts, uint64_t count_stride,
                                uint64_t n, int32_t swap, const uint8_t *orders,
-                               void *result, int32_t *result_ok, void *stream)
+                               void *result, int32_t *result_ok, void *stream,
+                               FilterLink link = FilterLink{ nullptr, nullptr })
 {
-    if (!result) return fail("mrpdr_wave_filter: NULL result");
+    if (!result && !link.node) return fail("mrpdr_wave_filter: NULL result");
     if (n && !values) return fail("mrpdr_wave_filter: NULL values");
-    if (op == MRPDR_AVG && n && !counts) return fail("mrpdr_wave_filter: AVG needs counts");
-    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE && shape != MRPDR_SHAPE_FLAT_SERIAL)
+    if (op == MRPDR_AVG && n && !counts && shape != SHAPE_COMBINE) return fail("mrpdr_wave_filter: AVG needs counts");
+    if (shape != MRPDR_SHAPE_FLAT && shape != MRPDR_SHAPE_TREE && shape != MRPDR_SHAPE_FLAT_SERIAL && shape != SHAPE_COMBINE)
         return fail("mrpdr_wave_filter: unknown shape %d", shape);
     if ((op == MRPDR_OR || op == MRPDR_AND) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T))
         return fail("mrpdr_wave_filter: bitwise operators need an integer type");
@@ -1312,16 +1354,16 @@ static int32_t filter_dispatch(const FilterWs &fw, int32_t op, int32_t type, int
     uint8_t *res = (uint8_t *)result;
     hipStream_t st = (hipStream_t)stream;
     switch (type) {
-    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_INT16_T:  return run_filter_op<int16_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_INT32_T:  return run_filter_op<int32_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_INT64_T:  return run_filter_op<int64_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_FLOAT_T:  return run_filter_op<float>(fw, op, shape, in, res, result_ok, st);
-    case MRPDR_DOUBLE_T: return run_filter_op<double>(fw, op, shape, in, res, result_ok, st);
+    case MRPDR_CHAR_T:   return run_filter_op<int8_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_UCHAR_T:  return run_filter_op<uint8_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_INT16_T:  return run_filter_op<int16_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_UINT16_T: return run_filter_op<uint16_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_INT32_T:  return run_filter_op<int32_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_UINT32_T: return run_filter_op<uint32_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_INT64_T:  return run_filter_op<int64_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_UINT64_T: return run_filter_op<uint64_t>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_FLOAT_T:  return run_filter_op<float>(fw, op, shape, in, res, result_ok, st, link);
+    case MRPDR_DOUBLE_T: return run_filter_op<double>(fw, op, shape, in, res, result_ok, st, link);
     }
     // the built-in filters accept exactly these ten types (src/FilterDefinitions.C:110-146)
     return fail("mrpdr_wave_filter: type %d is not a scalar the filters accept", type);
@@ -1358,6 +1400,40 @@ extern "C" int32_t mrpdr_wave_filter_mixed(mrpdr_ctx *c, int32_t op, int32_t typ
     if (n && !byteorders) return fail("mrpdr_wave_filter_mixed: NULL byteorders");
     return wave_filter(c, op, type, shape, values, value_stride, counts, count_stride, n, 0, n ? byteorders : nullptr,
                        result, result_ok, stream);
+}
+
+// ---------------------------------------------------------------------------
+// a wave in ranges: one reference filter call over packets that several GPUs (or several calls) hold
+// ---------------------------------------------------------------------------
+static_assert(sizeof(mrpdr_node) == sizeof(Partial) && offsetof(mrpdr_node, count) == offsetof(Partial, cnt) &&
+              offsetof(mrpdr_node, present) == offsetof(Partial, present), "mrpdr_node is the tree node the kernels exchange");
+
+extern "C" int32_t mrpdr_filter_is_chained(int32_t op, int32_t type)
+{
+    return (op == MRPDR_SUM || op == MRPDR_AVG) && (type == MRPDR_FLOAT_T || type == MRPDR_DOUBLE_T);
+}
+
+extern "C" int32_t mrpdr_wave_filter_partial(mrpdr_ctx *c, int32_t op, int32_t type,
+                                             const void *values, uint64_t value_stride,
+                                             const void *counts, uint64_t count_stride,
+                                             uint64_t n, int32_t swap,
+                                             const mrpdr_node *front, mrpdr_node *node, void *stream)
+{
+    if (!ctx_ready("mrpdr_wave_filter_partial", c)) return 0;
+    if (n > c->max_packets) return fail("mrpdr_wave_filter_partial: n exceeds the ctx limit");
+    if (!node) return fail("mrpdr_wave_filter_partial: NULL node");
+    return filter_dispatch(ctx_filter_ws(c), op, type, MRPDR_SHAPE_FLAT, values, value_stride, counts, count_stride, n, swap,
+                           nullptr, nullptr, nullptr, stream, FilterLink{ (const Partial *)front, (Partial *)node });
+}
+
+extern "C" int32_t mrpdr_wave_filter_combine(mrpdr_ctx *c, int32_t op, int32_t type, const mrpdr_node *nodes, uint64_t g,
+                                             void *result, int32_t *result_ok, void *stream)
+{
+    if (!ctx_ready("mrpdr_wave_filter_combine", c)) return 0;
+    if (g && !nodes) return fail("mrpdr_wave_filter_combine: NULL nodes");
+    if (!result) return fail("mrpdr_wave_filter_combine: NULL result");
+    return filter_dispatch(ctx_filter_ws(c), op, type, SHAPE_COMBINE, nodes, sizeof(mrpdr_node), nullptr, 0, g, 0, nullptr,
+                           result, result_ok, stream);
 }
 
 // ---------------------------------------------------------------------------

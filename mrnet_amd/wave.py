@@ -579,6 +579,44 @@ class Codec:
         _check(r, "mrpdr_wave_filter")
         return result, result_ok
 
+    # ---- one filter call over a wave held in ranges (several GPUs, or several calls) ----------
+    def is_chained(self, op, dtype):
+        """True for float / double SUM and AVG: the chain of roundings has to be continued from
+        range to range (front = the node the range before left), not re-associated."""
+        return bool(self._lib.mrpdr_filter_is_chained(op, int(dtype)))
+
+    def filter_partial_raw(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,
+                           front=None, node=None):
+        """The 16-byte node of a packet range (struct mrpdr_node as a uint8[16] device tensor);
+        front: the node of the packets in front of the range, or None."""
+        node = self.empty(16, torch.uint8) if node is None else node
+        _check(self._lib.mrpdr_wave_filter_partial(self.handle, op, int(dtype), values_ptr, value_stride, counts_ptr,
+                                                   count_stride, n, swap, _ptr(front), _ptr(node), _stream()),
+               "mrpdr_wave_filter_partial")
+        return node
+
+    def filter_partial_wire(self, op, fmt, wire, sender_bo=LITTLEENDIAN, front=None, node=None):
+        """filter_partial_raw straight on the wire bytes of a packed fixed-format wave (as filter_wire)."""
+        want = 2 if op == TFILTER_AVG else 1
+        if len(fmt) != want or not fmt.is_fixed or (want == 2 and fmt.types[1] != DataType.INT32_T):
+            raise PdrError("filter format must be '%T'" + (" %d'" if want == 2 else "'"))
+        if wire.offsets is not None:
+            raise PdrError("filter_partial_wire needs the packed layout")
+        base = wire.arena.data_ptr()
+        return self.filter_partial_raw(op, fmt.types[0], base, wire.stride, base + fmt.widths[0], wire.stride, wire.n,
+                                       int(sender_bo != LITTLEENDIAN), front, node)
+
+    def filter_combine(self, op, dtype, nodes, result=None, result_ok=None):
+        """nodes: uint8[g, 16] (or uint8[16 * g]) device tensor, range order -> (result, result_ok) of
+        the one reference call over the whole wave."""
+        result = self.empty(16, torch.uint8) if result is None else result
+        result_ok = self.empty(1, torch.int32) if result_ok is None else result_ok
+        nodes = nodes.contiguous()
+        _check(self._lib.mrpdr_wave_filter_combine(self.handle, op, int(dtype), _ptr(nodes), nodes.numel() // 16,
+                                                   _ptr(result), _ptr(result_ok), _stream()),
+               "mrpdr_wave_filter_combine")
+        return result, result_ok
+
     def filter_stats_raw(self, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap=0,
                          results=None, results_ok=None):
         """Min, Max and Avg of a '<T> %d' wave in one pass: (uint8[48], int32[3])."""

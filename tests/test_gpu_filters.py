@@ -286,8 +286,10 @@ def test_decode_and_filter_refusals_and_short_packets(codec):
 
 @pytest.mark.parametrize("opname,op", OPS)
 def test_sharded_wave_combine(codec, opname, op):
-    """A 1M-packet '%lf %d' wave in 8 packet ranges (one per GPU of a node): per-range tree
-    result on the GPU, then the rank-ordered last level -- against the oracle doing the same."""
+    """A 1M-packet '%lf %d' wave in 8 packet ranges (one per GPU of a node), in the declared-tree
+    reading (shape=SHAPE_TREE): per-range tree result on the GPU, then the ranks as the last tree
+    level -- against the oracle's tree of the same shape; held to 1e-6 relative of ONE flat fold over
+    the whole wave, which is what the default (SHAPE_FLAT, tests/test_gpu_ranges.py) returns exactly."""
     from mrnet_amd import dist as D
     n, world = 1 << 20, 8
     v = values_for(np.float64, n, 55, op)
@@ -310,13 +312,19 @@ def test_sharded_wave_combine(codec, opname, op):
     assert np.asarray(got[0]).tobytes() == np.asarray(want[0]).tobytes()
     if op == O.AVG:
         assert got[1] == want[1] == int(c.sum())
+    one_call = O.filter_flat(op, O.DOUBLE_T, v, c if op == O.AVG else None)
+    scale = float(np.sum(np.abs(v) * (c if op == O.AVG else 1))) / (float(c.sum()) if op == O.AVG else 1.0)
+    assert abs(float(got[0]) - float(one_call[0])) <= 1e-6 * max(scale, abs(float(one_call[0])))
     # single-process group: the sharded entry point degenerates to the local tree + one more level
     wire = W.WireWave(codec.to_device(arena), n, None, None, 12)
-    res1, ok1 = D.filter_wire_sharded(codec, op, fmt, wire) if op == O.AVG else (None, None)
     if op == O.AVG:
+        res1, ok1 = D.filter_wire_sharded(codec, op, fmt, wire, shape=W.SHAPE_TREE)
         whole = O.filter_tree(op, O.DOUBLE_T, v, c, W.TREE_FANINS)
         last = O.filter_flat(op, O.DOUBLE_T, np.array([whole[0]]), np.array([whole[1]], np.int32))
         assert np.asarray(W.result_value(res1, ok1, np.dtype(np.float64), op)[0]).tobytes() == np.asarray(last[0]).tobytes()
+        # and in the default reading: the one call's bits
+        res2, ok2 = D.filter_wire_sharded(codec, op, fmt, wire)
+        assert np.asarray(W.result_value(res2, ok2, np.dtype(np.float64), op)[0]).tobytes() == np.asarray(one_call[0]).tobytes()
 
 
 def test_bitwise_or_and_integer_percentiles(codec):
@@ -390,17 +398,60 @@ def test_result_written_to_pinned_host_memory(codec, n):
     flag = ok_h.numpy()
     for op in (W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX):
         res_d, ok_d = codec.filter_raw(op, W.DataType.INT32_T, vals.data_ptr(), 4, None, 0, n)
-        flag[0] = 0
+        flag[0] = RESULT_PENDING
         codec.filter_raw(op, W.DataType.INT32_T, vals.data_ptr(), 4, None, 0, n, result=res_h, result_ok=ok_h)
-        spins = 0
-        while flag[0] == 0 and spins < 50_000_000:
-            spins += 1
-        assert flag[0] == 1, "the result never arrived in host memory"
+        assert _poll(flag) == 1, "the result never arrived in host memory"
+        # the flag is stored last, behind a system-scope fence: whoever sees it sees the result bytes
+        seen = bytes(res_h.numpy())
         torch.cuda.synchronize()
-        assert bytes(res_h.numpy()) == bytes(res_d.cpu().numpy())
+        assert seen == bytes(res_h.numpy()) == bytes(res_d.cpu().numpy())
         want = O.filter_flat({W.TFILTER_SUM: O.SUM, W.TFILTER_MIN: O.MIN, W.TFILTER_MAX: O.MAX}[op], O.INT32_T,
                              vals.cpu().numpy())
         assert int(res_h.numpy()[:4].view(np.int32)[0]) == int(want[0])
+
+
+RESULT_PENDING = -1        # MRPDR_RESULT_PENDING of include/mrpdr.h
+
+
+def _poll(flag, limit=50_000_000):
+    spins = 0
+    while flag[0] == RESULT_PENDING and spins < limit:
+        spins += 1
+    return int(flag[0])
+
+
+def test_polling_ends_when_there_is_no_result(codec):
+    """An absent result (an empty wave; an AVG whose counts sum to zero) writes result_ok = 0: a final
+    value, distinct from the pending mark a polling host presets, so its loop ends -- for every kernel
+    that can write a result (tree, one tile, the float chain in its three forms, decode + filter)."""
+    res_h, ok_h = torch.zeros(16, dtype=torch.uint8).pin_memory(), torch.zeros(1, dtype=torch.int32).pin_memory()
+    flag = ok_h.numpy()
+    cases = []
+    for n in (0, 7, 5000, 20000):
+        for t, dt in ((W.DataType.INT32_T, torch.int32), (W.DataType.FLOAT_T, torch.float32), (W.DataType.DOUBLE_T, torch.float64)):
+            cases.append((n, t, dt, W.TFILTER_AVG))
+    cases += [(0, W.DataType.INT32_T, torch.int32, W.TFILTER_SUM), (0, W.DataType.FLOAT_T, torch.float32, W.TFILTER_SUM),
+              (0, W.DataType.DOUBLE_T, torch.float64, W.TFILTER_MIN)]
+    for n, t, dt, op in cases:
+        vals = torch.ones(max(n, 1), dtype=dt, device=codec.device)
+        cnts = torch.zeros(max(n, 1), dtype=torch.int32, device=codec.device)         # no weight at all
+        for shape in (W.SHAPE_FLAT, W.SHAPE_TREE, W.SHAPE_FLAT_SERIAL):
+            flag[0] = RESULT_PENDING
+            res_h.fill_(0xEE)
+            codec.filter_raw(op, t, vals.data_ptr(), vals.element_size(), cnts.data_ptr(), 4, n, 0, shape,
+                             result=res_h, result_ok=ok_h)
+            assert _poll(flag) == 0, (n, t, op, shape)
+            assert not res_h.numpy().any(), "an absent result is sixteen zero bytes"
+    # decode + filter of an empty wave and of a weightless one
+    fmt = W.Format("%d %d")
+    for n in (0, 3000):
+        rows = torch.zeros(max(n, 1) * 8, dtype=torch.uint8, device=codec.device)
+        wire = W.WireWave(rows, n, None, None, 8)
+        cols, ok = codec.alloc_columns(fmt, max(n, 1)), codec.empty(max(n, 1), torch.int32)
+        flag[0] = RESULT_PENDING
+        codec.decode_filter_into(fmt, wire, cols, ok, W.TFILTER_AVG, W.SHAPE_FLAT, result=res_h, result_ok=ok_h)
+        assert _poll(flag) == 0, n
+    torch.cuda.synchronize()
 
 
 import os  # noqa: E402

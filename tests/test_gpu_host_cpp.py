@@ -42,3 +42,18 @@ def test_filter_plugin_program():
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "MRNTEST_FAILURE" not in r.stdout
     assert r.stdout.count("MRNTEST_SUCCESS") == 4 * 3 * 5 * 4 + 1 + 4 * 3 * 6 + 1 + 4 * 3
+
+
+def test_rccl_combine_program():
+    """tests/host/test_rccl_combine.cpp: ncclCommInitAll over the visible devices, one thread per device,
+    the nodes of mrpdr_wave_filter_partial gathered (ncclAllGather) or relayed (ncclSend / ncclRecv /
+    ncclBroadcast) and combined; every rank's result against the reference's loops on the host.  One
+    device here: a communicator of one rank, RCCL on device memory all the same."""
+    exe = os.path.join(ROOT, "tests", "host", "test_rccl_combine")
+    assert os.path.exists(exe), "build it with `make` (it travels with the tree, prebuilt)"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=200, env=env)
+    print(r.stdout[-3000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "MRNTEST_FAILURE" not in r.stdout
+    assert "RCCL " in r.stdout and r.stdout.count("MRNTEST_SUCCESS") >= 8
