@@ -396,6 +396,7 @@ def small_wave_extras(codec):
     del big
     out.update(batched_small_waves_extra(dev))
     out.update(message_extra(codec))
+    out.update(host_to_host_extra(codec))
     assert float(r3[0][:8].view(torch.float64).item()) == float(v.min().item())
     assert float(r3[1][:8].view(torch.float64).item()) == float(v.max().item())
     return out
@@ -428,8 +429,13 @@ def batched_small_waves_extra(dev):
 
 def perfdata_extra(codec):
     """Config 5, array variant: one GPU's shard of 131,072 '%ad %ad %alf' packets with 8 doubles
-    each (the shape Stream::collect_PerfData emits), element-wise Avg as a two-level tree
-    (nodes of 256 children, then one node over the 512 results)."""
+    each (the shape Stream::collect_PerfData emits), element-wise Avg
+      - as a declared three-level tree, 32 x 64 x 64 (nodes of 32 packets, of 64 nodes, one node over
+        the 64 results: three launches with chains of 32, 64 and 64 dependent steps);
+      - as the two-level tree of the earlier rounds (256 x 512), for comparison;
+      - as ONE invocation over all packets (what the mirrors default to): doubles are a serial chain of
+        131,072 roundings per element; int64 data of the same shape does not depend on the grouping and
+        is folded as a tree of undivided nodes (the same bits as the serial loop)."""
     n, k = 131072, 8
     dev = codec.device
     ranks = W.Column(torch.arange(n, dtype=torch.int32, device=dev), torch.ones(n, dtype=torch.int64, device=dev),
@@ -437,16 +443,36 @@ def perfdata_extra(codec):
     vals = torch.randn(n * k, dtype=torch.float64, device=dev) * 1e-4 + 1e-3
     data = W.Column(vals, torch.full((n,), k, dtype=torch.int64, device=dev),
                     torch.arange(n + 1, dtype=torch.int64, device=dev) * k, n * k)
+    ivals = (vals * 1e9).to(torch.int64)
+    idata = W.Column(ivals, data.counts, data.offs, n * k)
     res = {}
 
-    def run():
-        res["o"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, group=256, out_cap=k)
-    t = time_call(run, 50)
-    out, out_len, out_rank = res["o"]
-    assert int(out_len.item()) == k and int(out_rank.item()) == -n
+    def tree3():
+        res["o"] = codec.filter_perfdata_levels(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, [32, 64, 0], out_cap=k)
+
+    def tree2():
+        res["o2"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, group=256, out_cap=k)
+
+    def flat():
+        res["f"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, group=0, out_cap=k)
+
+    def flat_i64():
+        res["i"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.INT64_T, ranks, idata, n, group=0, out_cap=k)
+    t3, t2 = time_call(tree3, 50), time_call(tree2, 50)
+    tf, ti = time_call(flat, 5), time_call(flat_i64, 50)
     want = vals.view(n, k).mean(dim=0)
-    assert torch.allclose(out[:k].view(torch.float64), want, rtol=1e-9)
-    return {"c5b_perfdata_avg_us_per_wave": round(t * 1e6, 1)}
+    for key in ("o", "o2", "f"):
+        out, out_len, out_rank = res[key]
+        assert int(out_len.item()) == k and int(out_rank.item()) == -n
+        assert torch.allclose(out[:k].view(torch.float64), want, rtol=1e-9)
+    out, out_len, out_rank = res["i"]
+    # (the int64 sums of this data do not wrap: the plain sum over all packets, divided once, truncating toward zero)
+    sums = ivals.view(n, k).sum(dim=0)
+    assert int(out_len.item()) == k and torch.equal(out[:k], torch.div(sums, n, rounding_mode="trunc"))
+    return {"c5b_perfdata_avg_us_per_wave": round(t3 * 1e6, 1), "c5b_perfdata_tree": "32 x 64 x 64",
+            "c5b_perfdata_avg_two_level_256_us_per_wave": round(t2 * 1e6, 1),
+            "c5b_perfdata_avg_flat_us_per_wave": round(tf * 1e6, 1),
+            "c5b_perfdata_avg_i64_flat_us_per_wave": round(ti * 1e6, 1)}
 
 
 def mixed_wave_extra(codec, n=65536, key="c4", align=16, amax=512):
@@ -546,6 +572,193 @@ def message_extra(codec):
         out["f1_%s_message_build_steady_us" % name] = round(tbs * 1e6, 1)
         out["f1_%s_message_parse_decode_steady_us" % name] = round(tps * 1e6, 1)
         out["f1_%s_message_mib" % name] = round(msg.numel() / 2**20, 1)
+    return out
+
+
+def host_to_host_extra(codec):
+    """The filter path and the mixed-format codec from host memory to host memory: what a tree node
+    pays per wave when its receive buffers are host memory (src/Message.C:48-199 reads the link into
+    host buffers, src/Filter.C:42-117 then runs the filter).  Wall time of the host thread from the
+    first copy's enqueue to the result being readable on the host; inputs and outputs pinned.
+      C2        65,536 x '%d' rows (256 KiB) up, decode + Sum (mrpdr_wave_decode_filter), the 16 result
+                bytes written by the kernel into pinned memory and polled there
+      C5 shard  131,072 x '%lf %d' rows (1.5 MiB) up, fused Min / Max / Avg, 48 result bytes polled
+      C4        65,536 mixed packets: wire up + decode to device columns; columns -> sizeof + encode +
+                wire down (18.8 MiB each way)
+    The oracle's time for the same waves is in cpu_baseline (host_to_host_cpu)."""
+    out = {}
+    dev = codec.device
+
+    def poll(flags):
+        spins = 0
+        while (flags == -1).any():
+            spins += 1
+            if spins > 100_000_000:
+                raise RuntimeError("the polled result never arrived")
+
+    # ---- C2 ----
+    n = 65536
+    fmt = W.Format("%d")
+    host_rows = torch.randint(-2**31, 2**31 - 1, (n,), dtype=torch.int32).pin_memory()
+    dev_rows = torch.empty(n, dtype=torch.int32, device=dev)
+    wire = W.WireWave(dev_rows.view(torch.uint8), n, None, None, 4)
+    cols, ok = codec.alloc_columns(fmt, n), torch.empty(n, dtype=torch.int32, device=dev)
+    res_h = torch.zeros(16, dtype=torch.uint8).pin_memory()
+    rok_h = torch.zeros(1, dtype=torch.int32).pin_memory()
+    call = codec.bind_decode_filter(fmt, wire, cols, ok, W.TFILTER_SUM, W.SHAPE_FLAT, res_h, rok_h)
+    flag = rok_h.numpy()
+
+    def c2():
+        flag[0] = -1
+        dev_rows.copy_(host_rows, non_blocking=True)
+        call()
+        poll(flag)
+    out["c2_host_to_host_us"] = round(time_call(c2, 200) * 1e6, 1)
+    assert int(res_h.numpy()[:4].view(np.int32)[0]) == int(host_rows.sum(dtype=torch.int32).item())
+    filt = codec.bind_filter(W.TFILTER_SUM, W.DataType.INT32_T, dev_rows.data_ptr(), 4, None, 0, n, 0, W.SHAPE_FLAT,
+                             res_h, rok_h, owners=(dev_rows,))
+
+    def c2_filter_only():                       # the fold alone, straight on the uploaded rows (no columns written)
+        flag[0] = -1
+        dev_rows.copy_(host_rows, non_blocking=True)
+        filt()
+        poll(flag)
+    out["c2_host_to_host_filter_only_us"] = round(time_call(c2_filter_only, 200) * 1e6, 1)
+
+    # ---- C5 shard ----
+    n5 = 131072
+    v = torch.randn(n5, dtype=torch.float64) * 1e-4 + 1e-3
+    rows = torch.empty((n5, 12), dtype=torch.uint8)
+    rows[:, :8] = v.view(torch.uint8).view(n5, 8)
+    rows[:, 8:] = torch.ones(n5, dtype=torch.int32).view(torch.uint8).view(n5, 4)
+    host5 = rows.view(-1).pin_memory()
+    dev5 = torch.empty(n5 * 12, dtype=torch.uint8, device=dev)
+    r48 = torch.zeros(48, dtype=torch.uint8).pin_memory()
+    ok3 = torch.zeros(3, dtype=torch.int32).pin_memory()
+    flags3 = ok3.numpy()
+    p5 = dev5.data_ptr()
+
+    def c5():
+        flags3[:] = -1
+        dev5.copy_(host5, non_blocking=True)
+        codec.filter_stats_raw(W.DataType.DOUBLE_T, p5, 12, p5 + 8, 12, n5, 0, r48, ok3)
+        poll(flags3)
+    out["c5_shard_host_to_host_us"] = round(time_call(c5, 200) * 1e6, 1)
+    assert float(r48.numpy()[:8].view(np.float64)[0]) == float(v.min().item())
+
+    # ---- C4 ----
+    n4 = 65536
+    fmt4 = W.Format("%d %uld %lf %s %auc")
+    rng = np.random.default_rng(4)
+    slen = np.minimum(rng.geometric(1.0 / 12.0, n4), 255).astype(np.uint64) + 1
+    alen = rng.integers(0, 513, n4).astype(np.uint64)
+    sbody = rng.integers(33, 127, int(slen.sum()), dtype=np.uint8)
+    sbody[np.cumsum(slen).astype(np.int64) - 1] = 0
+    cols4 = codec.columns_from_numpy(fmt4, [
+        rng.integers(-2**31, 2**31, n4).astype(np.int32), rng.integers(0, 2**63, n4).astype(np.uint64),
+        rng.uniform(-1e6, 1e6, n4), (slen, sbody), (alen, rng.integers(0, 256, int(alen.sum()), dtype=np.uint8))])
+    lens, offs, total = codec.sizeof(fmt4, cols4, n4, 16, 0)
+    wire4 = W.WireWave(torch.zeros(total, dtype=torch.uint8, device=dev), n4, offs, lens, 0)
+    codec.encode_into(fmt4, cols4, wire4)
+    host_wire = torch.empty(total, dtype=torch.uint8).pin_memory()
+    host_wire.copy_(wire4.arena)
+    host_offs, host_lens = offs.cpu().pin_memory(), lens.cpu().pin_memory()
+    d_offs, d_lens = torch.empty_like(offs), torch.empty_like(lens)
+    in_wire = W.WireWave(torch.empty(total, dtype=torch.uint8, device=dev), n4, d_offs, d_lens, 0)
+    dcols = codec.alloc_columns(fmt4, n4, capacities=[0, 0, 0, int(slen.sum()), int(alen.sum())])
+    ok4 = torch.empty(n4, dtype=torch.int32, device=dev)
+
+    def c4_in():            # the size vector's offsets / lengths travel with the wire, as a Message's do
+        in_wire.arena.copy_(host_wire, non_blocking=True)
+        d_offs.copy_(host_offs, non_blocking=True)
+        d_lens.copy_(host_lens, non_blocking=True)
+        codec.decode_into(fmt4, in_wire, dcols, ok4)
+        torch.cuda.synchronize()
+    out["c4_host_to_columns_us"] = round(time_call(c4_in, 30) * 1e6, 1)
+    assert bool(ok4.all()) and torch.equal(dcols[4].values.view(torch.uint8), cols4[4].values.view(torch.uint8))
+    host_out = torch.empty(total, dtype=torch.uint8).pin_memory()
+    out_lens_h, out_offs_h = torch.empty_like(host_lens), torch.empty_like(host_offs)
+
+    def c4_out():
+        codec.sizeof(fmt4, cols4, n4, 16, 0, want_total=False, lens=lens, offsets=offs)
+        codec.encode_into(fmt4, cols4, wire4)
+        host_out.copy_(wire4.arena, non_blocking=True)
+        out_lens_h.copy_(lens, non_blocking=True)
+        out_offs_h.copy_(offs, non_blocking=True)
+        torch.cuda.synchronize()
+    out["c4_columns_to_host_us"] = round(time_call(c4_out, 30) * 1e6, 1)
+    assert torch.equal(host_out, host_wire)
+    out["c4_wire_mib"] = round(total / 2**20, 1)
+    return out
+
+
+def host_to_host_cpu():
+    """The oracle's time (one core) for the waves of host_to_host_extra: what the node's existing CPU
+    path spends on the same work, host buffers in, host buffers out."""
+    from oracle import oracle as O
+    out = {}
+    rng = np.random.default_rng(4)
+    # C2: decode 65,536 x '%d', tfilter_Sum, one output packet (timed inside the C library)
+    out["c2_us"] = round(O.bench_small_wave(10, 65536) * 1e6, 1)
+    # C5 shard: decode 131,072 x '%lf %d', then Min, Max and Avg over the decoded values
+    n5 = 131072
+    c5 = [{"type": O.DOUBLE_T, "values": rng.normal(1e-3, 1e-4, n5)}, {"type": O.INT32_T, "values": np.ones(n5, np.int32)}]
+    a5, o5, l5 = O.wave_encode("%lf %d", c5, n5)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        d5, ok5 = O.wave_decode("%lf %d", a5, o5, l5, O.LITTLE)
+        for op in (O.MIN, O.MAX):
+            O.filter_flat(op, O.DOUBLE_T, d5[0]["values"])
+        O.filter_flat(O.AVG, O.DOUBLE_T, d5[0]["values"], d5[1]["values"])
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["c5_shard_us"] = round(best * 1e6, 1)
+    # C4: 65,536 mixed packets decoded to columns, and encoded from columns
+    n4 = 65536
+    slen = np.minimum(rng.geometric(1.0 / 12.0, n4), 255).astype(np.uint64) + 1
+    alen = rng.integers(0, 513, n4).astype(np.uint64)
+    sbody = rng.integers(33, 127, int(slen.sum()), dtype=np.uint8)
+    sbody[np.cumsum(slen).astype(np.int64) - 1] = 0
+
+    def offs_of(c):
+        o = np.zeros(c.size + 1, np.uint64)
+        np.cumsum(c, out=o[1:])
+        return o
+    c4 = [{"type": O.INT32_T, "values": rng.integers(-2**31, 2**31, n4).astype(np.int32)},
+          {"type": O.UINT64_T, "values": rng.integers(0, 2**63, n4).astype(np.uint64)},
+          {"type": O.DOUBLE_T, "values": rng.uniform(-1e6, 1e6, n4)},
+          {"type": O.STRING_T, "counts": slen, "offs": offs_of(slen), "values": sbody},
+          {"type": O.UCHAR_ARRAY_T, "counts": alen, "offs": offs_of(alen), "values": rng.integers(0, 256, int(alen.sum()), dtype=np.uint8)}]
+    t0 = time.perf_counter()
+    a4, o4, l4 = O.wave_encode("%d %uld %lf %s %auc", c4, n4)
+    out["c4_columns_to_host_us"] = round((time.perf_counter() - t0) * 1e6, 1)
+    t0 = time.perf_counter()
+    d4, ok4 = O.wave_decode("%d %uld %lf %s %auc", a4, o4, l4, O.LITTLE)
+    out["c4_host_to_columns_us"] = round((time.perf_counter() - t0) * 1e6, 1)
+    assert ok4.all()
+    # the fold alone: the 65,536-term float chain of tfilter_Sum on one host core (the decoded column is
+    # already there), beside flat_sum_f32_64k_us
+    vf = rng.standard_normal(65536).astype(np.float32)
+    best = None
+    for _ in range(20):
+        t0 = time.perf_counter()
+        O.filter_flat(O.SUM, O.FLOAT_T, vf)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["fold_only_us"] = round(best * 1e6, 1)
+    vd = rng.normal(1e-3, 1e-4, 65536)
+    best = None
+    for _ in range(20):
+        t0 = time.perf_counter()
+        O.filter_flat(O.AVG, O.DOUBLE_T, vd, np.ones(65536, np.int32))
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    out["fold_only_avg_f64_us"] = round(best * 1e6, 1)
+    # and the chain with everything per-packet taken away (a tight loop of dependent additions):
+    # the fastest a host core produces the same bits
+    out["fold_only_tight_loop_us"] = round(O.bench_chain(vf) * 1e6, 1)
+    out["fold_only_tight_loop_f64_us"] = round(O.bench_chain(vd) * 1e6, 1)
     return out
 
 
@@ -857,6 +1070,12 @@ def main():
             out["extra"] = extra
         if not a.no_cpu:
             out["cpu_baseline"] = cpu_baseline(min(a.cpu_packets, a.packets), a.elems, a.cpu_reps)
+            h2h = host_to_host_cpu()
+            out["cpu_baseline"]["fold_only_us"] = h2h.pop("fold_only_us")
+            out["cpu_baseline"]["fold_only_avg_f64_us"] = h2h.pop("fold_only_avg_f64_us")
+            out["cpu_baseline"]["fold_only_tight_loop_us"] = h2h.pop("fold_only_tight_loop_us")
+            out["cpu_baseline"]["fold_only_tight_loop_f64_us"] = h2h.pop("fold_only_tight_loop_f64_us")
+            out["cpu_baseline"]["host_to_host_us"] = h2h
     if world > 1:
         # (a failure here -- the same on every rank, the inputs are seeded -- must not cost the
         # headline line that is already measured: it is reported in the line instead)
@@ -872,26 +1091,27 @@ def main():
             rows[:, :8] = v.view(torch.uint8).view(n5, 8)
             rows[:, 8:] = torch.ones(n5, dtype=torch.int32, device="cuda").view(torch.uint8).view(n5, 4)
             w5 = W.WireWave(rows.view(-1), n5, None, None, 12)
-            for _ in range(3):
-                res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
-            barrier()
-            t5 = time.perf_counter()
-            for _ in range(20):
-                res5, ok5 = D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5)
-            barrier()
-            t5 = (time.perf_counter() - t5) / 20
+            def timed(fn, reps=20):
+                for _ in range(3):
+                    r = fn()
+                barrier()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    r = fn()
+                barrier()
+                return (time.perf_counter() - t) / reps, r
+            # ONE reference filter call over the whole wave (the default): nodes exchanged, the chain of
+            # a double Avg relayed in rank order -- and the declared-tree reading (ranks = one more level)
+            t5, (res5, ok5) = timed(lambda: D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5))
+            t5t, (res5t, ok5t) = timed(lambda: D.filter_wire_sharded(codec, W.TFILTER_AVG, fmt5, w5, shape=W.SHAPE_TREE))
             cnt5 = int(res5[8:12].view(torch.int32).item())
             assert int(ok5.item()) == 1 and cnt5 == n5 * world, "sharded Avg lost packets"
-            # the configuration as it is named: Min, Max and Avg fused per shard, one exchange for the three
-            for _ in range(3):
-                st5, oks5 = D.stats_wire_sharded(codec, fmt5, w5)
-            barrier()
-            t5s = time.perf_counter()
-            for _ in range(20):
-                st5, oks5 = D.stats_wire_sharded(codec, fmt5, w5)
-            barrier()
-            t5s = (time.perf_counter() - t5s) / 20
-            assert bool(oks5.all()) and torch.equal(st5[32:48], res5), "fused sharded Min/Max/Avg differs from the sharded Avg"
+            assert int(res5t[8:12].view(torch.int32).item()) == cnt5
+            # the configuration as it is named: Min, Max and Avg, one exchange for what can be gathered
+            t5s, (st5, oks5) = timed(lambda: D.stats_wire_sharded(codec, fmt5, w5))
+            t5st, (st5t, oks5t) = timed(lambda: D.stats_wire_sharded(codec, fmt5, w5, shape=W.SHAPE_TREE))
+            assert bool(oks5.all()) and torch.equal(st5[32:48], res5), "sharded Min/Max/Avg differs from the sharded Avg"
+            assert bool(oks5t.all()) and torch.equal(st5t[32:48], res5t) and torch.equal(st5t[:32], st5[:32])
             # the same for the performance-data shape: 131,072 x '%ad %ad %alf'[8] per rank, Avg, per-rank
             # output packets gathered (80 bytes each) and folded once more
             k5 = 8
@@ -900,20 +1120,24 @@ def main():
             colsp = codec.columns_from_numpy(fmtp, [
                 (onesp, (np.arange(n5, dtype=np.int32) + rank * n5)), (onesp, np.full(n5, k5, np.int32)),
                 (np.full(n5, k5, np.uint64), np.random.default_rng(50 + rank).normal(1e-3, 1e-4, n5 * k5))])
-            for _ in range(3):
-                pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
-            barrier()
-            t5b = time.perf_counter()
-            for _ in range(20):
-                pd5, pl5, pr5 = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5, fanin=256)
-            barrier()
-            t5b = (time.perf_counter() - t5b) / 20
+            t5b, (pd5, pl5, pr5) = timed(lambda: D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2],
+                                                                    n5, k5, fanin=256, shape=W.SHAPE_TREE))
             assert int(pl5.item()) == k5 and int(pr5.item()) == -n5 * world, "sharded PerfData lost ranks"
+            # one invocation over the whole wave: int64 states gathered (order-free), double states relayed
+            icol = W.Column((colsp[2].values * 1e9).to(torch.int64), colsp[2].counts, colsp[2].offs, n5 * k5)
+            t5bi, (pdi, pli, pri) = timed(lambda: D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.INT64_T, colsp[0], icol, n5, k5))
+            assert int(pli.item()) == k5 and int(pri.item()) == -n5 * world
+            t5bf, (pdf, plf, prf) = timed(lambda: D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, colsp[0], colsp[2], n5, k5), reps=3)
+            assert int(plf.item()) == k5 and int(prf.item()) == -n5 * world
             if rank == 0:
                 out["extra"] = {"c5_sharded_avg_us_per_wave": round(t5 * 1e6, 1), "c5_packets": n5 * world,
+                                "c5_sharded_avg_tree_us_per_wave": round(t5t * 1e6, 1),
                                 "c5_sharded_min_max_avg_us_per_wave": round(t5s * 1e6, 1),
+                                "c5_sharded_min_max_avg_tree_us_per_wave": round(t5st * 1e6, 1),
                                 "c5_avg": float(res5[:8].view(torch.float64).item()),
-                                "c5b_sharded_perfdata_avg_us_per_wave": round(t5b * 1e6, 1)}
+                                "c5b_sharded_perfdata_avg_tree_us_per_wave": round(t5b * 1e6, 1),
+                                "c5b_sharded_perfdata_avg_i64_one_call_us_per_wave": round(t5bi * 1e6, 1),
+                                "c5b_sharded_perfdata_avg_one_call_us_per_wave": round(t5bf * 1e6, 1)}
         except Exception as e:                          # noqa: BLE001
             print("rank %d: sharded filter leg failed: %r" % (rank, e), file=sys.stderr)
             if rank == 0:

@@ -183,7 +183,11 @@ int32_t     mrpdr_ctx_perf_plain_copy(mrpdr_ctx *ctx, void *dst, const void *src
 /* ---- format strings ------------------------------------------------------
  * Fmt2Type (src/DataElement.C:205-297) + the " \t\n%" tokenising of
  * Packet::pdr_packet_data (src/Packet.C:608-619), done once per format instead of
- * once per packet.  NULL on an unknown token or more than 32 tokens. */
+ * once per packet.  NULL on an unknown token.
+ * Deliberate deviation: a format of more than 32 tokens is refused (NULL) where the reference's
+ * tokenizer has no bound (src/Packet.C:608-619).  The field table travels to every kernel as an
+ * argument, which fixes its size; the reference's own formats stop at eleven tokens
+ * (tests/test_basic_FE.C:1345) and the formats of its own protocol have at most a handful (e.g. src/Network.C:1955). */
 mrpdr_fmt  *mrpdr_fmt_compile(const char *fmt);
 void        mrpdr_fmt_free(mrpdr_fmt *f);
 int32_t     mrpdr_fmt_nfields(const mrpdr_fmt *f);
@@ -551,12 +555,18 @@ int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *ctx, const mrpdr_column *in, u
  * data_len(last packet) elements by the rank total).  The output packet is
  * ([out_rank[0]], [out_len[0]], out_data[0 .. out_len[0])): out_data holds out_cap elements
  * (a longer result sets status bit 0 and out_len 0), out_len / out_rank are device pointers.
- *   group = 0 or >= n : one filter invocation over the n packets (a node with n children);
+ *   group = 0 or >= n : one filter invocation over the n packets (a node with n children), bit
+ *                       for bit.  uint64 / int64 data does not depend on how the packets are
+ *                       grouped (wrapping sums of data * nrank and of the ranks, ONE division at
+ *                       the end, src/FilterDefinitions.C:1084-1132; MIN / MAX from their fixed
+ *                       start values): given `scratch` of mrpdr_perfdata_scratch_bytes(n, 0,
+ *                       out_cap) bytes, waves of 2,048 packets and more are folded as a tree of
+ *                       undivided nodes (short chains side by side) instead of one chain over all
+ *                       n packets; without scratch, and for doubles (every addition rounds), the
+ *                       packets are folded one after the other;
  *   0 < group < n     : a two-level tree -- nodes of `group` consecutive packets, then one node
  *                       over their outputs (the filter runs at every level, as in an MRNet
- *                       tree: AVG divides and re-weights per level; integer SUM / MIN / MAX
- *                       give the bits of the one-node fold for any group, only faster: a
- *                       node folds its packets one after the other).  Needs `scratch` of
+ *                       tree: AVG divides and re-weights per level).  Needs `scratch` of
  *                       mrpdr_perfdata_scratch_bytes(n, group, out_cap) bytes, 16-byte aligned. */
 uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap);
 int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,
@@ -564,6 +574,50 @@ int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,
                             uint64_t group, void *out_data, uint64_t out_cap,
                             uint64_t *out_len, int32_t *out_rank,
                             void *scratch, uint64_t scratch_bytes, void *stream);
+
+/* The same filter as a declared tree of any depth: level l folds groups of fanins[l] consecutive
+ * packets of the level below (0: all of them) with one filter invocation per group, the way a tree of
+ * MRNet processes with those fan-ins runs tfilter_PerfData at every node (AVG divides and re-weights
+ * per node, the output of a node carries rank -total).  If the fan-ins leave more than one node, one
+ * more level folds them all.  nlevels <= 8.  Short arrays (out_cap <= 64) put many nodes into one
+ * workgroup: 131,072 packets as { 32, 64, 0 } are three launches with chains of 32, 64 and 64 steps.
+ * scratch: mrpdr_perfdata_levels_scratch_bytes(n, fanins, nlevels, out_cap) bytes, 16-byte aligned. */
+uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64_t *fanins, int32_t nlevels, uint64_t out_cap);
+int32_t mrpdr_wave_perfdata_levels(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                   const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n,
+                                   const uint64_t *fanins, int32_t nlevels, void *out_data, uint64_t out_cap,
+                                   uint64_t *out_len, int32_t *out_rank,
+                                   void *scratch, uint64_t scratch_bytes, void *stream);
+
+/* One tfilter_PerfData invocation over a wave that is held in packet ranges (one per GPU, rank order),
+ * the counterpart of mrpdr_wave_filter_partial / _combine: every range is folded into a STATE -- this
+ * header followed by `cap` accumulators of 8 bytes, nothing divided -- and the states combine into the
+ * output packet of the one invocation over the whole wave (src/FilterDefinitions.C:984-1132).
+ *   uint64 / int64 : no order between the ranges is needed (front = NULL everywhere); gather the
+ *                    states, combine all g of them;
+ *   double         : mrpdr_perfdata_is_chained() -- every addition rounds, and MIN / MAX keep the later
+ *                    operand when a comparison with a NaN is false: range r + 1 continues from the
+ *                    state range r left (front), the last state is the wave's; combine takes the LAST
+ *                    of the g states it is given.
+ * A range without packets (n = 0) hands `front` on (or an empty state).  scratch as for
+ * mrpdr_wave_perfdata(group = 0) (optional: integer ranges of 2,048 packets and more use it). */
+typedef struct mrpdr_perf_state {
+    uint64_t longest;      /* elements that have taken at least one packet */
+    uint64_t last;         /* data length of the last packet below (the elements AVG divides) */
+    int32_t  rank;         /* 0 - total number of ranks below: the rank value of the output packet */
+    uint32_t packets;      /* 0: no packet below */
+    uint64_t reserved;
+} mrpdr_perf_state;
+uint64_t mrpdr_perfdata_state_bytes(uint64_t cap);        /* sizeof(mrpdr_perf_state) + 8 * cap */
+int32_t  mrpdr_perfdata_is_chained(int32_t op, int32_t type);
+int32_t  mrpdr_wave_perfdata_partial(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                     const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n, uint64_t cap,
+                                     const void *front, void *state,
+                                     void *scratch, uint64_t scratch_bytes, void *stream);
+int32_t  mrpdr_wave_perfdata_combine(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                     const void *states, uint64_t g, uint64_t cap,
+                                     void *out_data, uint64_t out_cap, uint64_t *out_len, int32_t *out_rank,
+                                     void *stream);
 
 /* tfilter_IntEqClass (src/FilterDefinitions.C:812-902) over a decoded wave of "%aud %aud %aud"
  * packets (class values, members per class, members): the classes of all packets merged by

@@ -55,8 +55,9 @@ struct GpuFilterState {
     hipStream_t stream;
     uint8_t    *h_rows;       // pinned: the data buffers of the wave, one row per packet
     uint8_t    *h_orders;     // pinned: sender byte order of every packet
-    uint8_t    *d_rows, *d_orders, *d_result;
-    int32_t    *d_ok;
+    uint8_t    *d_rows, *d_orders;
+    uint8_t    *h_result;     // pinned, 16 result bytes + the int32 presence flag: the last kernel of a
+                              // filter call writes them here itself (no copy back is enqueued)
     size_t      cap_packets;
 };
 
@@ -76,8 +77,7 @@ void release(GpuFilterState *st)
     if (st->h_orders) (void)hipHostFree(st->h_orders);
     if (st->d_rows) (void)hipFree(st->d_rows);
     if (st->d_orders) (void)hipFree(st->d_orders);
-    if (st->d_result) (void)hipFree(st->d_result);
-    if (st->d_ok) (void)hipFree(st->d_ok);
+    if (st->h_result) (void)hipHostFree(st->h_result);
     if (st->stream) (void)hipStreamDestroy(st->stream);
     if (st->fmt) mrpdr_fmt_free(st->fmt);
     if (st->ctx) mrpdr_ctx_destroy(st->ctx);
@@ -101,8 +101,7 @@ GpuFilterState *state_for(void **slot, const char *fmt_text)
     st->fmt_text = strdup(fmt_text);
     if (!st->ctx || !st->fmt || !st->fmt_text ||
         !hip_ok(hipStreamCreateWithFlags(&st->stream, hipStreamNonBlocking), "hipStreamCreate") ||
-        !hip_ok(hipMalloc((void **)&st->d_result, 16), "hipMalloc") ||
-        !hip_ok(hipMalloc((void **)&st->d_ok, sizeof(int32_t)), "hipMalloc")) {
+        !hip_ok(hipHostMalloc((void **)&st->h_result, 32, hipHostMallocDefault), "hipHostMalloc")) {
         fprintf(stderr, "mrpdr filter: %s\n", mrpdr_last_error());
         release(st);
         return NULL;
@@ -157,37 +156,59 @@ void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector
     // (src/Packet.C:96); a packet made on this node has native order and possibly no header yet.
     const uint8_t native = (uint8_t)mrpdr_local_byteorder();
     bool foreign = false;
+    const char *same_fmt = fmt_text;      // the last format pointer found equal: packets that share it are not compared again
     for (size_t i = 0; i < n; i++) {
+        // every packet is an object of its own somewhere on the heap: the walk over them is a chain of
+        // cache misses, so the packet objects a few places ahead are asked for now (the pointer alone:
+        // no accessor is called on them, accessors take the packet's lock)
+        if (i + 12 < n) __builtin_prefetch(in[i + 12].get());
         const Packet &p = *in[i];
-        if (strcmp(p.get_FormatString(), fmt_text) != 0 || p.get_BufferLen() != row || !p.get_Buffer()) {
+        const char *pf = p.get_FormatString();
+        const char *buf = p.get_Buffer();
+        if ((pf != same_fmt && strcmp(pf, fmt_text) != 0) || p.get_BufferLen() != row || !buf) {
             fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
             return;
         }
-        memcpy(st->h_rows + i * row, p.get_Buffer(), row);
+        same_fmt = pf;
+        // rows are 1 to 12 bytes: fixed-size copies (a store or two) instead of a call with a run-time length
+        uint8_t *dst = st->h_rows + i * row;
+        switch (row) {
+        case 4:  memcpy(dst, buf, 4); break;
+        case 8:  memcpy(dst, buf, 8); break;
+        case 12: memcpy(dst, buf, 12); break;
+        case 2:  memcpy(dst, buf, 2); break;
+        case 1:  *dst = (uint8_t)*buf; break;
+        default: memcpy(dst, buf, row); break;
+        }
         const char *hdr = p.get_Header();
         const unsigned hdr_len = p.get_HeaderLen();
         st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
         foreign = foreign || st->h_orders[i] != native;
     }
     if (!hip_ok(hipMemcpyAsync(st->d_rows, st->h_rows, n * row, hipMemcpyHostToDevice, st->stream), "H2D")) return;
+    // The result comes back by itself: the filter's last kernel writes the 16 bytes and then, behind a
+    // system-scope fence, the presence flag into pinned memory; this thread presets the flag to
+    // "pending" and polls it (a bounded spin, then the stream is waited for the ordinary way).
+    uint8_t *result = st->h_result;
+    volatile int32_t *flag = (volatile int32_t *)(st->h_result + 16);
+    *flag = MRPDR_RESULT_PENDING;
     const void *counts = op == MRPDR_AVG ? st->d_rows + width : NULL;
     int32_t called;
     if (foreign) {
         if (!hip_ok(hipMemcpyAsync(st->d_orders, st->h_orders, n, hipMemcpyHostToDevice, st->stream), "H2D")) return;
         called = mrpdr_wave_filter_mixed(st->ctx, op, type, MRPDR_SHAPE_FLAT, st->d_rows, row, counts, row, n,
-                                         st->d_orders, st->d_result, st->d_ok, st->stream);
+                                         st->d_orders, result, (int32_t *)(st->h_result + 16), st->stream);
     } else {
         called = mrpdr_wave_filter(st->ctx, op, type, MRPDR_SHAPE_FLAT, st->d_rows, row, counts, row, n, 0,
-                                   st->d_result, st->d_ok, st->stream);
+                                   result, (int32_t *)(st->h_result + 16), st->stream);
     }
     if (!called) { fprintf(stderr, "%s: %s\n", name, mrpdr_last_error()); return; }
-    uint8_t result[16];
-    int32_t ok = 0;
-    if (!hip_ok(hipMemcpyAsync(result, st->d_result, 16, hipMemcpyDeviceToHost, st->stream), "D2H") ||
-        !hip_ok(hipMemcpyAsync(&ok, st->d_ok, sizeof ok, hipMemcpyDeviceToHost, st->stream), "D2H") ||
-        !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))
-        return;
-    if (!ok) return;            // e.g. an Avg whose counts sum to zero (the reference divides by zero there)
+    for (unsigned spins = 0; *flag == MRPDR_RESULT_PENDING && spins < (1u << 22); spins++)
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (*flag == MRPDR_RESULT_PENDING && !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize")) return;
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const int32_t ok = *flag;
+    if (ok != 1) return;        // 0: e.g. an Avg whose counts sum to zero (the reference divides by zero there)
     // the 16 result bytes are the output packet's fields in order: value, then for Avg the int count
     const void *fields[2] = { result, result + width };
     out.push_back(PacketPtr(new Packet(in[0]->get_StreamId(), in[0]->get_Tag(), fields, fmt_text)));

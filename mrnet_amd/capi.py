@@ -26,6 +26,8 @@ SYMBOLS = (
     "mrpdr_message_write_frame", "mrpdr_message_parse",
     "mrpdr_wave_filter", "mrpdr_filter_is_chained", "mrpdr_wave_filter_partial", "mrpdr_wave_filter_combine",
     "mrpdr_wave_decode_filter", "mrpdr_wave_filter_mixed", "mrpdr_wave_filter_noalloc", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
+    "mrpdr_perfdata_levels_scratch_bytes", "mrpdr_wave_perfdata_levels", "mrpdr_perfdata_state_bytes",
+    "mrpdr_perfdata_is_chained", "mrpdr_wave_perfdata_partial", "mrpdr_wave_perfdata_combine",
     "mrpdr_eqclass_scratch_bytes", "mrpdr_wave_int_eq_class",
 )
 
@@ -116,6 +118,13 @@ def load():
         "mrpdr_wave_array_concat": (i32, [vp, C.POINTER(Column), u64, C.POINTER(Column), vp]),
         "mrpdr_wave_array_concat_masked": (i32, [vp, C.POINTER(Column), u32, vp, u64, C.POINTER(Column), vp]),
         "mrpdr_perfdata_scratch_bytes": (u64, [u64, u64, u64]),
+        "mrpdr_perfdata_levels_scratch_bytes": (u64, [u64, C.POINTER(u64), i32, u64]),
+        "mrpdr_wave_perfdata_levels": (i32, [vp, i32, i32, C.POINTER(Column), C.POINTER(Column), u64, C.POINTER(u64), i32,
+                                             vp, u64, vp, vp, vp, u64, vp]),
+        "mrpdr_perfdata_state_bytes": (u64, [u64]),
+        "mrpdr_perfdata_is_chained": (i32, [i32, i32]),
+        "mrpdr_wave_perfdata_partial": (i32, [vp, i32, i32, C.POINTER(Column), C.POINTER(Column), u64, u64, vp, vp, vp, u64, vp]),
+        "mrpdr_wave_perfdata_combine": (i32, [vp, i32, i32, vp, u64, u64, vp, u64, vp, vp, vp]),
         "mrpdr_eqclass_scratch_bytes": (u64, [u64]),
         "mrpdr_wave_int_eq_class": (i32, [vp, C.POINTER(Column), C.POINTER(Column), C.POINTER(Column), u64,
                                           C.POINTER(Column), C.POINTER(Column), C.POINTER(Column), vp, u64, vp]),

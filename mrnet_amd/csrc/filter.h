@@ -678,6 +678,18 @@ struct PerfOut {
 
 #define PERF_STAGE_ELEMS 4096        // 32 KB of LDS for the data of one tile of packets
 
+// Raw nodes (perfnodes.h has the whole story): with in_lasts the packets are raw nodes of a level
+// below (added with weight one, `last` taken from the last of them); with out_lasts the node is left
+// raw (no AVG division, its `last` written); front = a raw node handed over by whoever folded the
+// packets in front of these (header, then the accumulators): the fold goes on from it.
+struct PerfRaw {
+    const uint64_t *in_lasts;
+    uint64_t *out_lasts;
+    const uint8_t *front;             // struct mrpdr_perf_state + accumulators, or NULL
+    uint32_t *out_packets;            // where a state's `packets` word goes, or NULL
+};
+struct PerfFront { uint64_t longest, last; int32_t rank; uint32_t packets; uint64_t reserved; };
+
 template <int OP, typename T> __device__ __forceinline__ T perf_fold(T acc, T x, int32_t nrank)
 {
     if (OP == MRPDR_SUM) return acc + x;
@@ -687,7 +699,7 @@ template <int OP, typename T> __device__ __forceinline__ T perf_fold(T acc, T x,
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
+__global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out, PerfRaw raw = PerfRaw{ nullptr, nullptr, nullptr, nullptr })
 {
     // The packets of the node are taken in tiles of 256: their lengths, offsets and rank counts
     // go to LDS (one packet per lane), and when the tile's data -- one contiguous run of the
@@ -708,7 +720,14 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
     __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
     uint32_t total = 0;
     uint64_t longest = 0, last = 0;
-    if (t == 0) { s_total = 0; s_longest = 0; }
+    PerfFront front = { 0, 0, 0, 0, 0 };
+    if (raw.front) {
+        front = *reinterpret_cast<const PerfFront *>(raw.front);
+        if (!front.packets) { front.longest = 0; front.last = 0; front.rank = 0; }
+        if (u < front.longest) acc = reinterpret_cast<const T *>(raw.front + sizeof(PerfFront))[u];
+        last = front.last;
+    }
+    if (t == 0) { s_total = (uint32_t)(0 - front.rank); s_longest = front.longest; }
     for (uint64_t p0 = i0; p0 < i1; p0 += MRPDR_TPB) {
         const uint32_t np = (uint32_t)((i1 - p0) < MRPDR_TPB ? (i1 - p0) : MRPDR_TPB);
         __syncthreads();
@@ -746,7 +765,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
             int32_t rank = 0;
             if (len && ld_rc) rank = in.rank_vals[ld_ro];
             const int32_t nrank = rank < 0 ? -rank : 1;
-            s_nrank[t] = nrank;
+            s_nrank[t] = raw.in_lasts ? 1 : nrank;         // (a raw node below is added as it is)
             my_ranks = len ? (uint32_t)nrank : 0u;
             my_len = len;
         }
@@ -805,7 +824,8 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
     __syncthreads();
     total = s_total;
     longest = s_longest;
-    if (OP == MRPDR_AVG && last && u < last) {
+    if (raw.in_lasts && i1 > i0) last = raw.in_lasts[i1 - 1];
+    if (!raw.out_lasts && OP == MRPDR_AVG && last && u < last) {
         acc = acc / (T)total;          // unsigned total converted to the element type, as the reference's /=
     }
     if (longest > out.stride) {                    // the result does not fit: say so, write nothing
@@ -818,5 +838,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out)
         out.ranks[g] = 0 - (int32_t)total;
         if (out.offs) out.offs[g] = g * out.stride;
         if (out.rank_counts) { out.rank_counts[g] = 1; out.rank_offs[g] = g; }
+        if (raw.out_lasts) raw.out_lasts[g] = last;
+        if (raw.out_packets) *raw.out_packets = 1u;
     }
 }

@@ -21,6 +21,7 @@
 #include "tile.h"
 #include "eqclass.h"
 #include "fused.h"
+#include "perfnodes.h"
 
 // ---------------------------------------------------------------------------
 // errors
@@ -1698,54 +1699,206 @@ extern "C" int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *c, const mrpdr_colu
 
 static inline uint64_t up16(uint64_t v) { return (v + 15) & ~(uint64_t)15; }
 
-extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
+// ---- tfilter_PerfData: levels of nodes ---------------------------------------------------------------
+#define PERF_MAX_LEVELS 8
+struct PerfPlan { int levels; uint64_t group[PERF_MAX_LEVELS + 1], nodes[PERF_MAX_LEVELS + 1]; };
+
+// Level l folds groups of fanins[l] consecutive packets of the level below (0: all of them); a level of
+// one node ends the tree, and if the fan-ins given leave several nodes one more level folds them all.
+static PerfPlan perf_plan(uint64_t n, const uint64_t *fanins, int nlevels)
 {
-    if (group == 0 || group >= n) return 0;
-    const uint64_t g = (n + group - 1) / group;
-    // data, lens, offs, rank_counts, rank_offs, ranks
-    return up16(g * out_cap * 8) + 4 * up16(g * 8) + up16(g * 4);
+    PerfPlan p;
+    p.levels = 0;
+    uint64_t m = n ? n : 1;
+    for (int l = 0; l < nlevels && l < PERF_MAX_LEVELS && (m > 1 || l == 0); l++) {
+        const uint64_t f = (fanins[l] == 0 || fanins[l] >= m) ? m : fanins[l];
+        p.group[p.levels] = f;
+        p.nodes[p.levels] = (m + f - 1) / f;
+        m = p.nodes[p.levels++];
+    }
+    if (m > 1 || p.levels == 0) { p.group[p.levels] = m; p.nodes[p.levels] = 1; p.levels++; }
+    return p;
 }
 
-template <int OP, typename T>
-static int32_t run_perfdata(mrpdr_ctx *c, const PerfIn &in, uint64_t out_cap, void *out_data, uint64_t *out_len,
-                            int32_t *out_rank, uint8_t *scratch, hipStream_t st)
+// what the nodes of one level take in the scratch: data, lens, offs, rank counts, rank offs, lasts, ranks
+static uint64_t perf_level_bytes(uint64_t nodes, uint64_t out_cap)
 {
-    const uint32_t xb = blocks_for(out_cap ? out_cap : 1, MRPDR_TPB);
-    if (in.group >= in.n) {
-        PerfOut o = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
-        k_perfdata<OP, T><<<dim3(xb, 1), MRPDR_TPB, 0, st>>>(in, o);
-        LAUNCHED("k_perfdata");
+    return up16(nodes * out_cap * 8) + 5 * up16(nodes * 8) + up16(nodes * 4);
+}
+
+static uint64_t perf_plan_bytes(const PerfPlan &p, uint64_t out_cap)
+{
+    uint64_t b = 0;
+    for (int l = 0; l + 1 < p.levels; l++) b += perf_level_bytes(p.nodes[l], out_cap);
+    return b;
+}
+
+// The order-free form of one invocation over integer data: raw nodes of 32 packets, of 64 nodes, then all.
+static const uint64_t PERF_FREE_FANINS[3] = { 32, 64, 0 };
+#define PERF_FREE_MIN 2048          // packets from which the raw tree is taken instead of the serial fold
+
+extern "C" uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64_t *fanins, int32_t nlevels, uint64_t out_cap)
+{
+    if (!fanins || nlevels <= 0) return 0;
+    return perf_plan_bytes(perf_plan(n, fanins, nlevels), out_cap);
+}
+
+extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
+{
+    if (group == 0 || group >= n)           // one invocation: integer data may take the raw tree
+        return n >= PERF_FREE_MIN ? perf_plan_bytes(perf_plan(n, PERF_FREE_FANINS, 3), out_cap) : 0;
+    const uint64_t two[2] = { group, 0 };
+    return perf_plan_bytes(perf_plan(n, two, 2), out_cap);
+}
+
+extern "C" uint64_t mrpdr_perfdata_state_bytes(uint64_t cap) { return sizeof(PerfState) + 8 * cap; }
+
+// every PerfDataMgr metric is folded in order where the order can change a bit: doubles round at every
+// addition, and their MIN / MAX keep the later operand whenever a comparison with a NaN is false
+extern "C" int32_t mrpdr_perfdata_is_chained(int32_t op, int32_t type)
+{
+    (void)op;
+    return type == MRPDR_DOUBLE_T;
+}
+
+static uint32_t perf_lanes(uint64_t out_cap)
+{
+    uint32_t w = PERF_MIN_W;
+    while (w < out_cap && w < MRPDR_TPB) w <<= 1;
+    return w;
+}
+
+// One level.  Several nodes of short arrays: k_perf_nodes (many nodes per workgroup); one node, or long
+// arrays: k_perfdata (a node per workgroup row, its packets staged 256 at a time).
+template <int OP, typename T>
+static int32_t launch_perf_level(const PerfIn &in, uint64_t nodes, const PerfOut &o, uint64_t out_cap, const PerfRaw &raw, hipStream_t st)
+{
+    const uint32_t w = perf_lanes(out_cap);
+    if (nodes > 1 && w <= 64) {
+        PerfLevel a = { in, o, raw.in_lasts, raw.out_lasts, raw.out_packets, w, (uint32_t)nodes };
+        const uint32_t npb = MRPDR_TPB / w;
+        k_perf_nodes<OP, T><<<dim3(1, (uint32_t)((nodes + npb - 1) / npb)), MRPDR_TPB, 0, st>>>(a);
+        LAUNCHED("k_perf_nodes");
         return 1;
     }
-    const uint64_t g = (in.n + in.group - 1) / in.group;
-    uint8_t *p = scratch;
-    void *d2 = p;                       p += up16(g * out_cap * 8);
-    uint64_t *lens2 = (uint64_t *)p;    p += up16(g * 8);
-    uint64_t *offs2 = (uint64_t *)p;    p += up16(g * 8);
-    uint64_t *rcnt2 = (uint64_t *)p;    p += up16(g * 8);
-    uint64_t *roff2 = (uint64_t *)p;    p += up16(g * 8);
-    int32_t *ranks2 = (int32_t *)p;
-    PerfOut o1 = { d2, out_cap, lens2, offs2, ranks2, rcnt2, roff2, c->status };
-    k_perfdata<OP, T><<<dim3(xb, (uint32_t)g), MRPDR_TPB, 0, st>>>(in, o1);
-    LAUNCHED("k_perfdata");
-    PerfIn in2 = { ranks2, rcnt2, roff2, d2, lens2, offs2, g, g };
-    PerfOut o2 = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
-    k_perfdata<OP, T><<<dim3(xb, 1), MRPDR_TPB, 0, st>>>(in2, o2);
+    const uint32_t xb = blocks_for(out_cap ? out_cap : 1, MRPDR_TPB);
+    k_perfdata<OP, T><<<dim3(xb, (uint32_t)nodes), MRPDR_TPB, 0, st>>>(in, o, raw);
     LAUNCHED("k_perfdata");
     return 1;
 }
 
-template <typename T>
-static int32_t run_perfdata_op(mrpdr_ctx *c, int32_t op, const PerfIn &in, uint64_t out_cap, void *out_data,
-                               uint64_t *out_len, int32_t *out_rank, uint8_t *scratch, hipStream_t st)
+// The levels of a plan, from the wave's columns to `final` (the one node of the last level).  raw: the
+// nodes in between are raw (nothing divided or re-weighted on the way up); raw_final / front: the last
+// node is left raw as well (a state: final_raw.out_lasts / out_packets say where), and, for a plan of
+// one level, continues from the state `front`.
+template <int OP, typename T>
+static int32_t run_perf_levels(mrpdr_ctx *c, PerfIn in, const PerfPlan &plan, bool raw, uint64_t out_cap, const PerfOut &final,
+                               const PerfRaw &final_raw, uint8_t *scratch, hipStream_t st)
+{
+    const uint64_t *in_lasts = nullptr;
+    uint8_t *p = scratch;
+    for (int l = 0; l < plan.levels; l++) {
+        const bool last_level = l + 1 == plan.levels;
+        const uint64_t nodes = plan.nodes[l];
+        in.group = plan.group[l];
+        PerfOut o;
+        PerfRaw r = { in_lasts, nullptr, nullptr, nullptr };
+        PerfIn next = in;
+        if (last_level) {
+            o = final;
+            r.out_lasts = final_raw.out_lasts;
+            r.out_packets = final_raw.out_packets;
+            if (plan.levels == 1) r.front = final_raw.front;
+        } else {
+            void *d2 = p;                       p += up16(nodes * out_cap * 8);
+            uint64_t *lens2 = (uint64_t *)p;    p += up16(nodes * 8);
+            uint64_t *offs2 = (uint64_t *)p;    p += up16(nodes * 8);
+            uint64_t *rcnt2 = (uint64_t *)p;    p += up16(nodes * 8);
+            uint64_t *roff2 = (uint64_t *)p;    p += up16(nodes * 8);
+            uint64_t *lasts2 = (uint64_t *)p;   p += up16(nodes * 8);
+            int32_t *ranks2 = (int32_t *)p;     p += up16(nodes * 4);
+            o = PerfOut{ d2, out_cap, lens2, offs2, ranks2, rcnt2, roff2, c->status };
+            if (raw) r.out_lasts = lasts2;
+            next = PerfIn{ ranks2, rcnt2, roff2, d2, lens2, offs2, nodes, nodes };
+            in_lasts = raw ? lasts2 : nullptr;
+        }
+        if (!launch_perf_level<OP, T>(in, nodes, o, out_cap, r, st)) return 0;
+        in = next;
+    }
+    return 1;
+}
+
+template <typename T, typename F>
+static int32_t perf_op(const char *who, int32_t op, F &&run)
 {
     switch (op) {
-    case MRPDR_SUM: return run_perfdata<MRPDR_SUM, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
-    case MRPDR_MIN: return run_perfdata<MRPDR_MIN, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
-    case MRPDR_MAX: return run_perfdata<MRPDR_MAX, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
-    case MRPDR_AVG: return run_perfdata<MRPDR_AVG, T>(c, in, out_cap, out_data, out_len, out_rank, scratch, st);
+    case MRPDR_SUM: return run(std::integral_constant<int, MRPDR_SUM>());
+    case MRPDR_MIN: return run(std::integral_constant<int, MRPDR_MIN>());
+    case MRPDR_MAX: return run(std::integral_constant<int, MRPDR_MAX>());
+    case MRPDR_AVG: return run(std::integral_constant<int, MRPDR_AVG>());
     }
-    return fail("mrpdr_wave_perfdata: unknown aggregation %d", op);
+    return fail("%s: unknown aggregation %d", who, op);
+}
+
+// type dispatch: PerfDataMgr metrics are uint64, int64 or double (src/FilterDefinitions.C:937-953)
+template <typename F>
+static int32_t perf_type(const char *who, int32_t type, F &&run)
+{
+    switch (type) {
+    case MRPDR_UINT64_T: return run((uint64_t)0);
+    case MRPDR_INT64_T:  return run((int64_t)0);
+    case MRPDR_DOUBLE_T: return run((double)0);
+    }
+    return fail("%s: type %d is not a performance-data type", who, type);
+}
+
+static int32_t perf_check(const char *who, mrpdr_ctx *c, const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n)
+{
+    if (!c || !ranks || !data) return fail("%s: NULL argument", who);
+    if (!ctx_ready(who, c)) return 0;
+    if (n > c->max_packets) return fail("%s: n exceeds the ctx limit", who);
+    if (n && (!ranks->counts || !ranks->offs || !data->counts || !data->offs)) return fail("%s: columns need counts and offs", who);
+    return 1;
+}
+
+static int32_t perf_run_plan(const char *who, mrpdr_ctx *c, int32_t op, int32_t type, const PerfIn &in, const PerfPlan &plan, bool raw,
+                             uint64_t out_cap, const PerfOut &final, const PerfRaw &final_raw, void *scratch, uint64_t scratch_bytes,
+                             hipStream_t st)
+{
+    const uint64_t need = perf_plan_bytes(plan, out_cap);
+    if (need && (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15u)))
+        return fail("%s: this fold needs %llu bytes of 16-byte aligned scratch", who, (unsigned long long)need);
+    for (int l = 0; l < plan.levels; l++)
+        if (plan.nodes[l] > 65535ull * (MRPDR_TPB / PERF_MIN_W)) return fail("%s: more than %u nodes on one level", who, 65535u * (MRPDR_TPB / PERF_MIN_W));
+    return perf_type(who, type, [&](auto tv) {
+        typedef decltype(tv) T;
+        return perf_op<T>(who, op, [&](auto opv) {
+            return run_perf_levels<decltype(opv)::value, T>(c, in, plan, raw, out_cap, final, final_raw, (uint8_t *)scratch, st);
+        });
+    });
+}
+
+extern "C" int32_t mrpdr_wave_perfdata_levels(mrpdr_ctx *c, int32_t op, int32_t type,
+                                              const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n,
+                                              const uint64_t *fanins, int32_t nlevels, void *out_data, uint64_t out_cap,
+                                              uint64_t *out_len, int32_t *out_rank,
+                                              void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    const char *who = "mrpdr_wave_perfdata_levels";
+    if (!perf_check(who, c, ranks, data, n)) return 0;
+    if (!out_len || !out_rank) return fail("%s: NULL argument", who);
+    if (n == 0) return fail("%s: empty wave (the reference emits nothing)", who);
+    if (!fanins || nlevels <= 0 || nlevels > PERF_MAX_LEVELS) return fail("%s: 1 to %d levels", who, PERF_MAX_LEVELS);
+    if (out_cap && !out_data) return fail("%s: NULL out_data", who);
+    PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts, data->offs, n, n };
+    PerfOut final = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
+    // a level of nodes of more than 65,535 ... is checked in perf_run_plan
+    const PerfPlan plan = perf_plan(n, fanins, nlevels);
+    if (perf_lanes(out_cap) > 64)
+        for (int l = 0; l < plan.levels; l++)
+            if (plan.nodes[l] > 65535) return fail("%s: more than 65535 nodes of long arrays on one level", who);
+    return perf_run_plan(who, c, op, type, in, plan, false, out_cap, final, PerfRaw{ nullptr, nullptr, nullptr, nullptr }, scratch,
+                         scratch_bytes, (hipStream_t)stream);
 }
 
 extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
@@ -1754,31 +1907,91 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
                                        uint64_t *out_len, int32_t *out_rank,
                                        void *scratch, uint64_t scratch_bytes, void *stream)
 {
-    if (!c || !ranks || !data || !out_len || !out_rank) return fail("mrpdr_wave_perfdata: NULL argument");
-    if (!ctx_ready("mrpdr_wave_perfdata", c)) return 0;
-    if (n == 0) return fail("mrpdr_wave_perfdata: empty wave (the reference emits nothing)");
-    if (n > c->max_packets) return fail("mrpdr_wave_perfdata: n exceeds the ctx limit");
-    if (!ranks->counts || !ranks->offs || !data->counts || !data->offs)
-        return fail("mrpdr_wave_perfdata: columns need counts and offs");
-    if (out_cap && !out_data) return fail("mrpdr_wave_perfdata: NULL out_data");
-    if (group == 0 || group > n) group = n;
-    if (group < n) {
-        const uint64_t need = mrpdr_perfdata_scratch_bytes(n, group, out_cap);
-        if (!scratch || scratch_bytes < need || ((uintptr_t)scratch & 15u))
-            return fail("mrpdr_wave_perfdata: a two-level fold needs %llu bytes of 16-byte aligned scratch",
-                        (unsigned long long)need);
-        if ((n + group - 1) / group > 65535) return fail("mrpdr_wave_perfdata: more than 65535 first-level nodes");
+    const char *who = "mrpdr_wave_perfdata";
+    if (!perf_check(who, c, ranks, data, n)) return 0;
+    if (!out_len || !out_rank) return fail("%s: NULL argument", who);
+    if (n == 0) return fail("%s: empty wave (the reference emits nothing)", who);
+    if (out_cap && !out_data) return fail("%s: NULL out_data", who);
+    if (type != MRPDR_UINT64_T && type != MRPDR_INT64_T && type != MRPDR_DOUBLE_T)
+        return fail("%s: type %d is not a performance-data type", who, type);
+    PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts, data->offs, n, n };
+    PerfOut final = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
+    const PerfRaw none = { nullptr, nullptr, nullptr, nullptr };
+    if (group == 0 || group >= n) {
+        // One invocation.  Integer data does not depend on the grouping (raw nodes, one division at the
+        // top): with room for the nodes it is computed as a tree of short chains; doubles, and callers
+        // without scratch, fold the packets one after the other.
+        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, 3);
+        const bool can = type != MRPDR_DOUBLE_T && n >= PERF_FREE_MIN && scratch && !((uintptr_t)scratch & 15u) &&
+                         scratch_bytes >= perf_plan_bytes(free_plan, out_cap) && perf_lanes(out_cap) <= 64;
+        if (can) return perf_run_plan(who, c, op, type, in, free_plan, true, out_cap, final, none, scratch, scratch_bytes, (hipStream_t)stream);
+        const uint64_t all[1] = { 0 };
+        return perf_run_plan(who, c, op, type, in, perf_plan(n, all, 1), false, out_cap, final, none, nullptr, 0, (hipStream_t)stream);
     }
-    PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts,
-                  data->offs, n, group };
+    if ((n + group - 1) / group > 65535 && perf_lanes(out_cap) > 64) return fail("%s: more than 65535 first-level nodes", who);
+    const uint64_t two[2] = { group, 0 };
+    return perf_run_plan(who, c, op, type, in, perf_plan(n, two, 2), false, out_cap, final, none, scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+// ---- a wave's PerfData fold in ranges (one per GPU) --------------------------------------------------
+extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t type,
+                                               const mrpdr_column *ranks, const mrpdr_column *data, uint64_t n, uint64_t cap,
+                                               const void *front, void *state, void *scratch, uint64_t scratch_bytes, void *stream)
+{
+    const char *who = "mrpdr_wave_perfdata_partial";
+    if (!perf_check(who, c, ranks, data, n)) return 0;
+    if (!state || ((uintptr_t)state & 7u)) return fail("%s: state must be an 8-byte aligned device buffer", who);
+    if (type != MRPDR_UINT64_T && type != MRPDR_INT64_T && type != MRPDR_DOUBLE_T)
+        return fail("%s: type %d is not a performance-data type", who, type);
+    const bool chained = mrpdr_perfdata_is_chained(op, type) != 0;
+    if (front && !chained) return fail("%s: integer ranges need no order: front must be NULL (combine all states)", who);
+    if (front && ((uintptr_t)front & 7u)) return fail("%s: front must be 8-byte aligned", who);
     hipStream_t st = (hipStream_t)stream;
-    switch (type) {
-    case MRPDR_UINT64_T: return run_perfdata_op<uint64_t>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
-    case MRPDR_INT64_T:  return run_perfdata_op<int64_t>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
-    case MRPDR_DOUBLE_T: return run_perfdata_op<double>(c, op, in, out_cap, out_data, out_len, out_rank, (uint8_t *)scratch, st);
+    const uint64_t bytes = mrpdr_perfdata_state_bytes(cap);
+    if (n == 0) {           // no packet here: the state in front passes through (or "nothing" does)
+        if (front) HIP_OK(hipMemcpyAsync(state, front, bytes, hipMemcpyDeviceToDevice, st));
+        else HIP_OK(hipMemsetAsync(state, 0, bytes, st));
+        return 1;
     }
-    // PerfDataMgr metrics are uint64, int64 or double (src/FilterDefinitions.C:937-953)
-    return fail("mrpdr_wave_perfdata: type %d is not a performance-data type", type);
+    uint8_t *sp = (uint8_t *)state;
+    PerfState *h = (PerfState *)sp;
+    HIP_OK(hipMemsetAsync(state, 0, sizeof(PerfState), st));
+    PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts, data->offs, n, n };
+    PerfOut final = { sp + sizeof(PerfState), cap, &h->longest, nullptr, &h->rank, nullptr, nullptr, c->status };
+    PerfRaw raw = { nullptr, &h->last, (const uint8_t *)front, &h->packets };
+    const uint64_t all[1] = { 0 };
+    PerfPlan plan = perf_plan(n, all, 1);
+    if (!chained && n >= PERF_FREE_MIN && perf_lanes(cap) <= 64) {
+        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, 3);
+        if (scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_plan_bytes(free_plan, cap)) plan = free_plan;
+    }
+    return perf_run_plan(who, c, op, type, in, plan, true, cap, final, raw, scratch, scratch_bytes, st);
+}
+
+extern "C" int32_t mrpdr_wave_perfdata_combine(mrpdr_ctx *c, int32_t op, int32_t type, const void *states, uint64_t g, uint64_t cap,
+                                               void *out_data, uint64_t out_cap, uint64_t *out_len, int32_t *out_rank, void *stream)
+{
+    const char *who = "mrpdr_wave_perfdata_combine";
+    if (!c || !out_len || !out_rank) return fail("%s: NULL argument", who);
+    if (!ctx_ready(who, c)) return 0;
+    if (g == 0 || !states) return fail("%s: no states", who);
+    if ((uintptr_t)states & 7u) return fail("%s: states must be 8-byte aligned", who);
+    if (out_cap && !out_data) return fail("%s: NULL out_data", who);
+    const uint64_t stride = mrpdr_perfdata_state_bytes(cap);
+    const uint8_t *sp = (const uint8_t *)states;
+    if (mrpdr_perfdata_is_chained(op, type)) { sp += (g - 1) * stride; g = 1; }     // relayed: the last state holds the whole fold
+    PerfOut o = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
+    const uint64_t span = cap > out_cap ? cap : out_cap;
+    const uint32_t xb = blocks_for(span ? span : 1, MRPDR_TPB);
+    hipStream_t st = (hipStream_t)stream;
+    return perf_type(who, type, [&](auto tv) {
+        typedef decltype(tv) T;
+        return perf_op<T>(who, op, [&](auto opv) {
+            k_perf_combine<decltype(opv)::value, T><<<xb, MRPDR_TPB, 0, st>>>(sp, g, stride, o);
+            LAUNCHED("k_perf_combine");
+            return 1;
+        });
+    });
 }
 
 // ---------------------------------------------------------------------------

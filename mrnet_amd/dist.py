@@ -193,13 +193,25 @@ def unpack_perfdata(rows, cap):
     return rank_col, data_col
 
 
-def perfdata_sharded(codec, op, dtype, ranks, data, n, cap, group=None, fanin=0):
+def perfdata_sharded(codec, op, dtype, ranks, data, n, cap, group=None, fanin=0, shape=W.SHAPE_FLAT):
     """tfilter_PerfData over a wave spread over the ranks of `group`; ranks / data are this rank's
-    decoded columns (n packets), cap bounds the result length.  fanin > 0 folds the rank's own
-    packets as a two-level tree (nodes of `fanin` packets, then one node over them) before the
-    exchange -- a flat fold of a large shard is one long serial chain per element.  Every rank
-    returns the same (out_data, out_len, out_rank)."""
-    out, out_len, out_rank = codec.filter_perfdata(op, dtype, ranks, data, n, group=fanin, out_cap=cap)
-    rows = gather_rows(pack_perfdata(out, out_len, out_rank, cap), group)
-    rank_col, data_col = unpack_perfdata(rows, cap)
-    return codec.filter_perfdata(op, dtype, rank_col, data_col, rows.shape[0], out_cap=cap)
+    decoded columns (n packets), cap bounds the result length.  Every rank returns the same
+    (out_data, out_len, out_rank).
+    SHAPE_FLAT: ONE filter invocation over the whole wave (src/FilterDefinitions.C:984-1132 over all
+    packets): every rank folds its range into an undivided state; integer states are gathered and
+    combined, double states -- a chain of roundings -- are relayed in rank order.
+    SHAPE_TREE: the ranks as a tree level: every rank folds its shard into one output packet (fanin > 0:
+    as a two-level tree of its own first), the packets are gathered and folded once more by the same
+    filter, as the children of the root (AVG divides and re-weights per level)."""
+    if shape == W.SHAPE_TREE:
+        out, out_len, out_rank = codec.filter_perfdata(op, dtype, ranks, data, n, group=fanin, out_cap=cap)
+        rows = gather_rows(pack_perfdata(out, out_len, out_rank, cap), group)
+        rank_col, data_col = unpack_perfdata(rows, cap)
+        return codec.filter_perfdata(op, dtype, rank_col, data_col, rows.shape[0], out_cap=cap)
+    nbytes = codec.perfdata_state_bytes(cap)
+    if codec.perfdata_is_chained(op, dtype):
+        state = relay_node(lambda front: codec.perfdata_partial(op, dtype, ranks, data, n, cap, front),
+                           lambda: codec.empty(nbytes, torch.uint8), group)
+        return codec.perfdata_combine(op, dtype, state, cap)
+    states = gather_rows(codec.perfdata_partial(op, dtype, ranks, data, n, cap), group)
+    return codec.perfdata_combine(op, dtype, states, cap)

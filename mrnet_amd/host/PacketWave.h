@@ -338,6 +338,7 @@ class PacketWave {
     {
         if (!fmt_) throw PdrError("mrpdr_fmt_compile");
         hdr_len_ = hdr_len;
+        hdr_region_bytes_ = (uint64_t)n * hdr_len;
         d_hdrs_.upload(hdrs, (size_t)n * hdr_len, wc_.stream);
         d_arena_.upload(bufs, buf_bytes, wc_.stream);
         d_offs_.upload(buf_offsets, 8 * n, wc_.stream);
@@ -374,6 +375,7 @@ class PacketWave {
         in_message_ = true;
         have_hdrs_ = false;             // the headers lie between the data buffers: get_Headers re-encodes them
         msg_pre_ = pre;
+        hdr_region_bytes_ = msg_bytes - pre;        // what was received, not what the buffer could hold
         decode_pdr_header();
     }
 
@@ -584,7 +586,9 @@ class PacketWave {
         DeviceBuffer d_sid, d_tag, d_src, d_bo, d_ok;
         d_sid.resize(4 * n_); d_tag.resize(4 * n_); d_src.resize(4 * n_); d_bo.resize(n_); d_ok.resize(4 * n_);
         const uint8_t *hdr_base = in_message_ ? d_msg_.ptr<uint8_t>() + msg_pre_ : d_hdrs_.ptr<uint8_t>();
-        const uint64_t hdr_bytes = in_message_ ? d_msg_.bytes() - msg_pre_ : d_hdrs_.bytes();
+        // the bound for untrusted header offsets is the length of what was uploaded (a DeviceBuffer's
+        // own size is its capacity: at least 16 bytes, and it never shrinks)
+        const uint64_t hdr_bytes = hdr_region_bytes_;
         if (!mrpdr_wave_decode_headers(wc_.ctx, fmt_, n_, hdr_base, hdr_bytes, in_message_ ? d_hoffs_.ptr<uint64_t>() : nullptr,
                                        in_message_ ? d_hlens_.ptr<uint64_t>() : nullptr, hdr_len_,
                                        d_sid.ptr<uint32_t>(), d_tag.ptr<int32_t>(), d_src.ptr<uint32_t>(),
@@ -675,6 +679,7 @@ class PacketWave {
     DeviceBuffer d_msg_, d_hoffs_, d_hlens_;   // a wave received as one Message: decoded in place
     bool in_message_ = false;
     uint64_t msg_pre_ = 0;
+    uint64_t hdr_region_bytes_ = 0; // bytes of the uploaded header block / of the message behind its preamble
     std::vector<DeviceBuffer> d_values_, d_counts_, d_coffs_, d_subc_, d_subo_;
     std::vector<mrpdr_column> cols_;
     std::vector<uint64_t> totals_;

@@ -320,11 +320,8 @@ def tfilter_PerfData(ipackets, aggr_id, group=0):
         return _from_columns(ipackets, fmt, [codec.array_concat_masked(cols[0], 4, mask, n),
                                              codec.array_concat_masked(cols[1], 4, mask, n),
                                              codec.array_concat_masked(cols[2], 8, mask, n)])
-    if group == 0 and n > 2048 and aggr_id != W.TFILTER_AVG and _PERF_TYPES[fmt.text] != W.DataType.DOUBLE_T:
-        # integer SUM / MIN / MAX do not depend on the fold order (wrap-around adds, and every level
-        # starts from the same initial value), so the one-node result can be computed as a two-level
-        # tree: the same bits without a serial chain over all n packets
-        group = 256
+    # (group == 0, one invocation: for integer data the library folds large waves as a tree of
+    # undivided nodes -- the same bits without a serial chain over all n packets; doubles are a chain)
     data, out_len, out_rank = codec.filter_perfdata(aggr_id, _PERF_TYPES[fmt.text], cols[0], cols[2], n, group)
     # output packet: ([-total_nranks], [len], data[0:len]); the length lives on the device
     one = torch.ones(1, dtype=torch.int64, device=codec.device)

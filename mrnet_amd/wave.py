@@ -372,33 +372,63 @@ class Codec:
 
     # ---- calls bound once -------------------------------------------------------------------
     # A node that handles wave after wave of one stream calls the same entry points with the same
-    # buffers every time.  bind_* converts the arguments to their C form once (structs, pointers,
-    # the current HIP stream) and returns a function that only makes the call.
-    def _bound(self, name, *args):
+    # buffers every time.  bind_* converts the arguments to their C form once (structs, raw device
+    # pointers, the HIP stream that is current AT BIND TIME) and returns a function that only makes
+    # the call.  The function holds on to the objects its pointers come from (wire, columns, ok,
+    # result tensors: `call.owners`), so the buffers cannot be freed under it; it does not follow a
+    # tensor that the caller REPLACES in one of those objects afterwards, nor a change of the
+    # current torch stream: bind again after either.
+    def _bound(self, name, owners, *args):
         fn = getattr(self._lib, name)
 
         def call():
             if not fn(*args):
                 raise PdrError("%s: %s" % (name, capi.last_error()))
         call.keep = args                  # the ctypes structures must outlive the closure's calls
+        call.owners = owners              # ... and so must the tensors their pointers point into
         return call
 
+    @staticmethod
+    def _tensors_of(*things):
+        """The tensors behind wires, columns and plain tensors (what a bound call must keep alive)."""
+        out = []
+        for x in things:
+            if x is None:
+                continue
+            if isinstance(x, torch.Tensor):
+                out.append(x)
+            elif isinstance(x, WireWave):
+                out += [t for t in (x.arena, x.offsets, x.lens) if t is not None]
+            elif isinstance(x, Column):
+                out += [t for t in (x.values, x.counts, x.offs, x.sub_counts, x.sub_offs) if t is not None]
+            elif isinstance(x, (list, tuple)):
+                out += Codec._tensors_of(*x)
+            else:
+                out.append(x)             # (a Format: its handle is an argument too)
+        return out
+
     def bind_decode(self, fmt, wire, cols, ok, sender_bo=LITTLEENDIAN):
-        return self._bound("mrpdr_wave_decode", self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
+        return self._bound("mrpdr_wave_decode", self._tensors_of(fmt, wire, cols, ok),
+                           self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
                            sender_bo, _c_columns(cols), _ptr(ok), _stream())
 
     def bind_encode(self, fmt, cols, wire):
-        return self._bound("mrpdr_wave_encode", self.handle, fmt.handle, _c_columns(cols), wire.n,
+        return self._bound("mrpdr_wave_encode", self._tensors_of(fmt, wire, cols),
+                           self.handle, fmt.handle, _c_columns(cols), wire.n,
                            C.byref(wire.c_struct()), _stream())
 
     def bind_decode_filter(self, fmt, wire, cols, ok, op, shape, result, result_ok, sender_bo=LITTLEENDIAN):
-        return self._bound("mrpdr_wave_decode_filter", self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
+        return self._bound("mrpdr_wave_decode_filter", self._tensors_of(fmt, wire, cols, ok, result, result_ok),
+                           self.handle, fmt.handle, C.byref(wire.c_struct()), wire.n,
                            sender_bo, _c_columns(cols), _ptr(ok), op, shape, _ptr(result), _ptr(result_ok),
                            _stream())
 
     def bind_filter(self, op, dtype, values_ptr, value_stride, counts_ptr, count_stride, n, swap, shape,
-                    result, result_ok):
-        return self._bound("mrpdr_wave_filter", self.handle, op, int(dtype), shape, values_ptr, value_stride,
+                    result, result_ok, owners=()):
+        """values_ptr / counts_ptr are raw device addresses: pass the tensors they point into as
+        `owners` to have the bound call keep them alive."""
+        return self._bound("mrpdr_wave_filter", self._tensors_of(result, result_ok, list(owners)),
+                           self.handle, op, int(dtype), shape, values_ptr, value_stride,
                            counts_ptr, count_stride, n, swap, _ptr(result), _ptr(result_ok), _stream())
 
     def decode(self, fmt, wire, sender_bo=LITTLEENDIAN):
@@ -662,6 +692,51 @@ class Codec:
                                           _ptr(out), out_cap, _ptr(out_len), _ptr(out_rank),
                                           _ptr(scratch), need, _stream())
         _check(r, "mrpdr_wave_perfdata")
+        return out, out_len, out_rank
+
+    def filter_perfdata_levels(self, op, dtype, ranks, data, n, fanins, out_cap=None):
+        """tfilter_PerfData as a declared tree: level l folds groups of fanins[l] packets of the level
+        below (0 = all), one filter invocation per group.  Returns (out_data, out_len, out_rank)."""
+        if out_cap is None:
+            out_cap = int(data.counts.max().item()) if n else 0
+        fan = (C.c_uint64 * len(fanins))(*[int(f) for f in fanins])
+        out = self.empty(max(out_cap, 1), torch.int64)
+        out_len, out_rank = self.empty(1, torch.int64), self.empty(1, torch.int32)
+        need = int(self._lib.mrpdr_perfdata_levels_scratch_bytes(n, fan, len(fanins), out_cap))
+        scratch = self.empty(max(need, 16), torch.uint8) if need else None
+        a, b = ranks.c_struct(), data.c_struct()
+        _check(self._lib.mrpdr_wave_perfdata_levels(self.handle, op, int(dtype), C.byref(a), C.byref(b), n, fan, len(fanins),
+                                                    _ptr(out), out_cap, _ptr(out_len), _ptr(out_rank), _ptr(scratch), need,
+                                                    _stream()), "mrpdr_wave_perfdata_levels")
+        return out, out_len, out_rank
+
+    # ---- one PerfData invocation over a wave held in ranges -----------------------------------
+    def perfdata_is_chained(self, op, dtype):
+        return bool(self._lib.mrpdr_perfdata_is_chained(op, int(dtype)))
+
+    def perfdata_state_bytes(self, cap):
+        return int(self._lib.mrpdr_perfdata_state_bytes(cap))
+
+    def perfdata_partial(self, op, dtype, ranks, data, n, cap, front=None, state=None):
+        """The state (struct mrpdr_perf_state + cap accumulators, a uint8 device tensor) of a packet
+        range; front: the state of the packets in front (doubles only)."""
+        state = self.empty(self.perfdata_state_bytes(cap), torch.uint8) if state is None else state
+        need = int(self._lib.mrpdr_perfdata_scratch_bytes(n, 0, cap))
+        scratch = self.empty(max(need, 16), torch.uint8) if need else None
+        a, b = ranks.c_struct(), data.c_struct()
+        _check(self._lib.mrpdr_wave_perfdata_partial(self.handle, op, int(dtype), C.byref(a), C.byref(b), n, cap, _ptr(front),
+                                                     _ptr(state), _ptr(scratch), need, _stream()), "mrpdr_wave_perfdata_partial")
+        return state
+
+    def perfdata_combine(self, op, dtype, states, cap, out_cap=None):
+        """states: uint8[g, state_bytes] device tensor in range order -> (out_data, out_len, out_rank)."""
+        out_cap = cap if out_cap is None else out_cap
+        states = states.contiguous()
+        g = states.numel() // self.perfdata_state_bytes(cap)
+        out = self.empty(max(out_cap, 1), torch.int64)
+        out_len, out_rank = self.empty(1, torch.int64), self.empty(1, torch.int32)
+        _check(self._lib.mrpdr_wave_perfdata_combine(self.handle, op, int(dtype), _ptr(states), g, cap, _ptr(out), out_cap,
+                                                     _ptr(out_len), _ptr(out_rank), _stream()), "mrpdr_wave_perfdata_combine")
         return out, out_len, out_rank
 
     def int_eq_class(self, vals, memcnts, mems, n):

@@ -290,6 +290,22 @@ def bench_small_wave(reps, n=4, value=1):
     return t
 
 
+def bench_chain(vals, reps=50):
+    """Seconds per tight left fold (the chain of additions alone) of a float32 / float64 column on one
+    host core; checked against filter_flat's bits."""
+    vals = np.ascontiguousarray(vals)
+    assert vals.dtype in (np.float32, np.float64)
+    fn = lib().orc_bench_chain
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    out = np.zeros(1, vals.dtype)
+    t = fn(int(vals.dtype == np.float64), _ptr(vals), vals.size, reps, _ptr(out))
+    ref = filter_flat(SUM, DOUBLE_T if vals.dtype == np.float64 else FLOAT_T, vals)
+    if out.tobytes() != np.asarray(ref[0]).tobytes():
+        raise RuntimeError("orc_bench_chain: the tight fold differs from the oracle's fold")
+    return t
+
+
 def filter_tree(op, t, vals, cnt, fanin):
     vals = np.ascontiguousarray(vals, dtype=elem_dtype(t))
     if cnt is not None:

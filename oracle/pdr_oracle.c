@@ -1123,3 +1123,34 @@ done:
     free(in); free(dec); free(ok); free(offs); free(lens); free(arena);
     return per_wave;
 }
+
+/* The left fold of tfilter_Sum over an already decoded float / double column with everything the
+ * reference does per packet taken away (no shared_ptr, no lock, no type switch: sum() of
+ * src/FilterDefinitions.C:1925-1964 inlined for one type): the dependent chain of additions and
+ * nothing else, i.e. the fastest a host core can produce the reference's bits.  Seconds per fold. */
+double orc_bench_chain(int is_double, const void *vals, uint64_t n, uint64_t reps, void *out)
+{
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (is_double) {
+        const double *v = (const double *)vals;
+        double r = 0;
+        for (uint64_t k = 0; k < reps; k++) {
+            r = 0;
+            for (uint64_t i = 0; i < n; i++) r = r + v[i];
+            __asm__ volatile("" : : "x"(r) : "memory");
+        }
+        memcpy(out, &r, 8);
+    } else {
+        const float *v = (const float *)vals;
+        float r = 0;
+        for (uint64_t k = 0; k < reps; k++) {
+            r = 0;
+            for (uint64_t i = 0; i < n; i++) r = r + v[i];
+            __asm__ volatile("" : : "x"(r) : "memory");
+        }
+        memcpy(out, &r, 4);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec)) / (double)(reps ? reps : 1);
+}

@@ -213,6 +213,7 @@ int32_t orc_filter_int_eq_class(const uint32_t *vals, const uint64_t *val_counts
  * receives the last result (n x value, wrapping).
  */
 double orc_bench_small_wave(uint64_t reps, uint64_t n, int32_t value, int32_t *sum);
+double orc_bench_chain(int is_double, const void *vals, uint64_t n, uint64_t reps, void *out);
 
 #ifdef __cplusplus
 }

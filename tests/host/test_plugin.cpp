@@ -331,10 +331,118 @@ static void test_eq_class(uint64_t n, int order_mode)
                 (order_mode == 2 ? "mixed" : order_mode ? "big" : "little") + ")", ok);
 }
 
-int main()
+// ---- --time: what a wave costs through the plugin, host memory in, host memory out ------------------
+#include <chrono>
+
+static double now_us()
+{
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Wall time per wave of mrpdr_Sum ('%d'), mrpdr_Avg ('%lf %d') and mrpdr_ArrayConcat ('%ad' of eight
+// elements) for growing waves, the filter state kept between waves as MRNet keeps it; beside each the
+// time of the gather loop alone (the plugin's host part: format check and row copy per packet) and of
+// the fold written out on the host over the same packet buffers with nothing else around it (no
+// Packet decode, no DataElement, no lock: a lower bound for any CPU filter, far below the reference's
+// own per-packet path).  One JSON line on stdout.
+static int time_mode()
+{
+    MRN::TopologyLocalInfo here, *info = &here;
+    PacketPtr params;
+    printf("{\"plugin_us_per_wave\": {");
+    bool first = true;
+    for (uint64_t n : { (uint64_t)4, (uint64_t)64, (uint64_t)1024, (uint64_t)16384, (uint64_t)65536 }) {
+        std::vector<PacketPtr> in_d, in_lf, in_a, out, rev;
+        std::vector<int32_t> vd(n), cnt(n, 1);
+        std::vector<double> vlf(n);
+        for (uint64_t i = 0; i < n; i++) {
+            vd[i] = (int32_t)(i * 2654435761u); vlf[i] = 1e-3 + 1e-7 * (double)(i % 1000);
+            const void *f1[1] = { &vd[i] };
+            const void *f2[2] = { &vlf[i], &cnt[i] };
+            int32_t arr[8];
+            for (int k = 0; k < 8; k++) arr[k] = (int32_t)(i + k);
+            in_d.push_back(received(1073741834u, 100, "%d", f1, 0));
+            in_lf.push_back(received(1073741834u, 100, "%lf %d", f2, 0));
+            in_a.push_back(received_array("%ad", arr, 8, 4, 0));
+        }
+        const int reps = n <= 1024 ? 300 : (n <= 16384 ? 100 : 40);
+        double t_sum, t_avg, t_cat, t_gather, t_fold, t_fold_avg;
+        void *s1 = NULL, *s2 = NULL, *s3 = NULL;
+        for (int w = 0; w < 5; w++) { out.clear(); mrpdr_Sum(in_d, out, rev, &s1, params, *info); }
+        double t0 = now_us();
+        for (int r = 0; r < reps; r++) { out.clear(); mrpdr_Sum(in_d, out, rev, &s1, params, *info); }
+        t_sum = (now_us() - t0) / reps;
+        int32_t want = 0;
+        for (uint64_t i = 0; i < n; i++) want = (int32_t)((uint32_t)want + (uint32_t)vd[i]);
+        bool ok = out.size() == 1 && !memcmp(out[0]->get_Buffer(), &want, 4);
+        for (int w = 0; w < 5; w++) { out.clear(); mrpdr_Avg(in_lf, out, rev, &s2, params, *info); }
+        t0 = now_us();
+        for (int r = 0; r < reps; r++) { out.clear(); mrpdr_Avg(in_lf, out, rev, &s2, params, *info); }
+        t_avg = (now_us() - t0) / reps;
+        double acc = 0; int32_t total = 0;
+        for (uint64_t i = 0; i < n; i++) { acc = acc + vlf[i] * (double)cnt[i]; total += cnt[i]; }
+        acc = acc / (double)total;
+        ok = ok && out.size() == 1 && !memcmp(out[0]->get_Buffer(), &acc, 8);
+        for (int w = 0; w < 3; w++) { out.clear(); mrpdr_ArrayConcat(in_a, out, rev, &s3, params, *info); }
+        t0 = now_us();
+        for (int r = 0; r < reps / 4 + 1; r++) { out.clear(); mrpdr_ArrayConcat(in_a, out, rev, &s3, params, *info); }
+        t_cat = (now_us() - t0) / (reps / 4 + 1);
+        ok = ok && out.size() == 1 && out[0]->get_BufferLen() == 8 + 32 * n;
+        // the plugin's own host part: what it does per packet before the copy to the device
+        std::vector<uint8_t> rows(4 * n), orders(n);
+        t0 = now_us();
+        for (int r = 0; r < reps; r++) {
+            const char *fmt_text = in_d[0]->get_FormatString(), *same = fmt_text;
+            for (uint64_t i = 0; i < n; i++) {
+                const Packet &p = *in_d[i];
+                const char *pf = p.get_FormatString();
+                if ((pf != same && strcmp(pf, fmt_text) != 0) || p.get_BufferLen() != 4) { ok = false; break; }
+                same = pf;
+                memcpy(&rows[4 * i], p.get_Buffer(), 4);
+                orders[i] = (uint8_t)p.get_Header()[p.get_HeaderLen() - 1];
+            }
+            __asm__ volatile("" : : "r"(rows.data()), "r"(orders.data()) : "memory");
+        }
+        t_gather = (now_us() - t0) / reps;
+        // the fold on the host over the packets' own buffers
+        t0 = now_us();
+        for (int r = 0; r < reps; r++) {
+            int32_t sres = 0;
+            for (uint64_t i = 0; i < n; i++) { int32_t x; memcpy(&x, in_d[i]->get_Buffer(), 4); sres = (int32_t)((uint32_t)sres + (uint32_t)x); }
+            __asm__ volatile("" : : "r"(sres) : "memory");
+            ok = ok && sres == want;
+        }
+        t_fold = (now_us() - t0) / reps;
+        t0 = now_us();
+        for (int r = 0; r < reps; r++) {
+            double a = 0; int32_t tc = 0;
+            for (uint64_t i = 0; i < n; i++) {
+                double x; int32_t c; memcpy(&x, in_lf[i]->get_Buffer(), 8); memcpy(&c, in_lf[i]->get_Buffer() + 8, 4);
+                a = a + x * (double)c; tc += c;
+            }
+            a = a / (double)tc;
+            __asm__ volatile("" : : "x"(a) : "memory");
+            ok = ok && a == acc;
+        }
+        t_fold_avg = (now_us() - t0) / reps;
+        release(static_cast<GpuFilterState *>(s1));
+        release(static_cast<GpuFilterState *>(s2));
+        release_var(static_cast<VarState *>(s3));
+        printf("%s\"%llu\": {\"mrpdr_Sum_d\": %.1f, \"mrpdr_Avg_lf\": %.1f, \"mrpdr_ArrayConcat_ad8\": %.1f, "
+               "\"gather_loop_only\": %.2f, \"host_fold_sum_d\": %.2f, \"host_fold_avg_lf\": %.2f, \"ok\": %s}",
+               first ? "" : ", ", (unsigned long long)n, t_sum, t_avg, t_cat, t_gather, t_fold, t_fold_avg, ok ? "true" : "false");
+        first = false;
+        if (!ok) failures++;
+    }
+    printf("}}\n");
+    return failures ? 1 : 0;
+}
+
+int main(int argc, char **argv)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { printf("MRNTEST_FAILURE: no HIP device\n"); return 1; }
+    if (argc > 1 && !strcmp(argv[1], "--time")) return time_mode();
     for (uint64_t n : { (uint64_t)1, (uint64_t)4, (uint64_t)1025, (uint64_t)70000 })
         for (int mode = 0; mode < 3; mode++) {
             test_type<int32_t>("%d", n, mode);

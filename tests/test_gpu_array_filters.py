@@ -303,3 +303,105 @@ def test_perfdata_integer_folds_do_not_depend_on_the_tree(codec, t, op):
     got_len = int(W.Codec.to_numpy(cols[2].counts).view(np.uint64)[0])
     assert got_len == ref[1].size and int(W.Codec.to_numpy(cols[0].values).view(np.int32)[0]) == ref[0]
     assert np.array_equal(W.Codec.to_numpy(cols[2].values).view(np.uint64)[:got_len], ref[1].view(np.uint64))
+
+
+def _perf_cols(codec, t, ranks, data, n):
+    fmt = W.Format(PERF_FMT[t])
+    nel = (np.ones(n, np.uint64), data[0].astype(np.int32))
+    return codec.columns_from_numpy(fmt, [ranks, nel, data])
+
+
+def _perf_result(t, out, out_len, out_rank):
+    torch.cuda.synchronize()
+    k = int(out_len.item())
+    return int(out_rank.item()), W.Codec.to_numpy(out).view(O.elem_dtype(t))[:k]
+
+
+@pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T, O.DOUBLE_T])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG])
+@pytest.mark.parametrize("n,kmax,same,fanins", [(5000, 8, True, [32, 64, 0]), (5000, 8, False, [7, 5, 3]),
+                                                (40000, 8, False, [32, 64, 0]), (3000, 40, False, [16, 0]),
+                                                (3000, 100, False, [16, 4, 0]), (70, 8, True, [32, 64, 0]),
+                                                (1, 8, True, [32, 0])])
+def test_perfdata_declared_trees_of_any_depth(codec, t, op, n, kmax, same, fanins):
+    """mrpdr_wave_perfdata_levels: the filter applied level by level over the declared fan-ins (many
+    nodes per workgroup for short arrays), against the oracle applying its one-invocation restatement
+    over the same tree.  Bits, doubles included (same order of additions)."""
+    ranks, data = perf_wave(n, t, seed=3 * n + op + t + len(fanins), kmax=kmax, same_len=same, aggregated=True)
+    # (fan-ins that leave several nodes: the library folds them in one more level)
+    ref = O.filter_perfdata_tree(op, t, ranks, data, fanins if fanins[-1] == 0 else fanins + [0])
+    cols = _perf_cols(codec, t, ranks, data, n)
+    got = _perf_result(t, *codec.filter_perfdata_levels(op, t, cols[0], cols[2], n, fanins, out_cap=kmax))
+    assert got[0] == ref[0] and got[1].size == ref[1].size
+    assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (got[1][:4], ref[1][:4])
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG])
+def test_perfdata_integer_one_invocation_is_parallel_and_exact(codec, t, op):
+    """One invocation over 131,072 integer packets: the library folds it as a tree of undivided nodes
+    (wrapping sums of data * nrank and of the ranks, ONE division at the top,
+    src/FilterDefinitions.C:1084-1132) -- against the oracle's serial loop over all packets, and against
+    the device's own serial fold (no scratch).  Ragged lengths, aggregated ranks, a last packet shorter
+    than the longest (AVG divides only its elements), and a last packet without data (no division)."""
+    n = 131072
+    for variant in range(3):
+        ranks, data = perf_wave(n, t, seed=40 + variant + op, kmax=8, same_len=(variant == 0), aggregated=True)
+        lens, vals = data
+        if variant == 2:
+            lens = lens.copy()
+            cut = int(lens[:-1].sum())
+            lens[-1] = 0
+            data = (lens, vals[:cut])
+        ref = O.filter_perfdata(op, t, ranks, data)
+        cols = _perf_cols(codec, t, ranks, data, n)
+        par = _perf_result(t, *codec.filter_perfdata(op, t, cols[0], cols[2], n, group=0, out_cap=8))
+        assert par[0] == ref[0] and np.array_equal(par[1].view(np.uint64), ref[1].view(np.uint64)), (variant, par, ref)
+        # the serial fold of the same call (no scratch handed over)
+        import ctypes as C
+        from mrnet_amd import capi
+        out = codec.empty(8, torch.int64)
+        out_len, out_rank = codec.empty(1, torch.int64), codec.empty(1, torch.int32)
+        a, b = cols[0].c_struct(), cols[2].c_struct()
+        assert capi.load().mrpdr_wave_perfdata(codec.handle, op, int(t), C.byref(a), C.byref(b), n, 0, out.data_ptr(), 8,
+                                               out_len.data_ptr(), out_rank.data_ptr(), None, 0,
+                                               torch.cuda.current_stream().cuda_stream) == 1
+        ser = _perf_result(t, out, out_len, out_rank)
+        assert ser[0] == ref[0] and np.array_equal(ser[1].view(np.uint64), ref[1].view(np.uint64)), variant
+    assert codec.status() == 0
+
+
+@pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T, O.DOUBLE_T])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG])
+def test_perfdata_in_ranges_equals_one_invocation(codec, t, op):
+    """mrpdr_wave_perfdata_partial / _combine: a wave in 2, 3 and 8 packet ranges (as the GPUs of a node
+    hold it) against ONE oracle invocation over the WHOLE wave -- integer states gathered, double states
+    relayed (each range continues from the state in front).  Ragged ranges with empty ones, NaNs in
+    double data (MIN / MAX keep the later operand when a comparison is false)."""
+    for n, kmax in ((20000, 8), (5000, 33), (700, 100)):
+        ranks, data = perf_wave(n, t, seed=11 * n + op + t, kmax=kmax, aggregated=True)
+        if t == O.DOUBLE_T and op in (W.TFILTER_MIN, W.TFILTER_MAX):
+            data[1][:: max(1, data[1].size // 50)] = np.nan
+        ref = O.filter_perfdata(op, t, ranks, data)
+        ro = np.zeros(n + 1, np.int64); np.cumsum(ranks[0], out=ro[1:])
+        do = np.zeros(n + 1, np.int64); np.cumsum(data[0], out=do[1:])
+        chained = codec.perfdata_is_chained(op, t)
+        assert chained == (t == O.DOUBLE_T)
+        for edges in ([0, n // 2, n], [0, n // 3, n // 3, n - 5, n], [0] + [n * r // 8 for r in range(1, 8)] + [n], [0, 0, n, n]):
+            states, front = [], None
+            for lo, hi in zip(edges[:-1], edges[1:]):
+                rk = (ranks[0][lo:hi], ranks[1][ro[lo]:ro[hi]])
+                dd = (data[0][lo:hi], data[1][do[lo]:do[hi]])
+                if hi > lo:
+                    cols = _perf_cols(codec, t, rk, dd, hi - lo)
+                    st = codec.perfdata_partial(op, t, cols[0], cols[2], hi - lo, kmax, front if chained else None)
+                else:
+                    empty = W.Column(None, None, None, 0)
+                    st = codec.perfdata_partial(op, t, empty, empty, 0, kmax, front if chained else None)
+                states.append(st)
+                front = st
+            got = _perf_result(t, *codec.perfdata_combine(op, t, torch.stack(states), kmax))
+            assert got[0] == ref[0] and got[1].size == ref[1].size, (n, edges, got, ref)
+            assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, edges, got[1][:4], ref[1][:4])
+    assert codec.status() == 0

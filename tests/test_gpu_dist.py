@@ -115,10 +115,19 @@ def _worker(rank, world, port, q):
         fmt = W.Format("%ad %ad %alf")
         cols = codec.columns_from_numpy(fmt, [(rc[lo:hi], rv[lo:hi]), (rc[lo:hi], np.full(hi - lo, K, np.int32)),
                                               (dc[lo:hi], dv[lo * K:hi * K])])
-        pd, plen, prank = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, cols[0], cols[2], hi - lo, K)
+        pd, plen, prank = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, cols[0], cols[2], hi - lo, K,
+                                             shape=W.SHAPE_TREE)
+        # one invocation over the whole wave: the double states relayed, the integer states gathered
+        pdf, plf, prf = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.DOUBLE_T, cols[0], cols[2], hi - lo, K)
+        icols = codec.columns_from_numpy(W.Format("%ad %ad %ald"), [
+            (rc[lo:hi], rv[lo:hi]), (rc[lo:hi], np.full(hi - lo, K, np.int32)),
+            (dc[lo:hi], (dv[lo * K:hi * K] * 1000).astype(np.int64))])
+        pdi, pli, pri = D.perfdata_sharded(codec, W.TFILTER_AVG, W.DataType.INT64_T, icols[0], icols[2], hi - lo, K)
         torch.cuda.synchronize()
+        flat_perf = (pdf.cpu().numpy().copy(), int(plf.item()), int(prf.item()), pdi.cpu().numpy().copy(), int(pli.item()),
+                     int(pri.item()))
         q.put((rank, res.cpu().numpy().copy(), int(ok.item()), pd.cpu().numpy().copy(), int(plen.item()),
-               int(prank.item()), codec.status(), exact, flat_avg))
+               int(prank.item()), codec.status(), exact, flat_avg, flat_perf))
     finally:
         dist.destroy_process_group()
 
@@ -142,7 +151,13 @@ def test_two_ranks_on_one_gpu():
     one_call = O.filter_flat(O.AVG, O.DOUBLE_T, vals, cnts)
     rc, rv, dc, dv = _perf_wave(N, K)
     tree = O.filter_perfdata_tree(O.AVG, O.DOUBLE_T, (rc, rv), (dc, dv), [N // 2, 0])
-    for rank, res, ok, pd, plen, prank, status, exact, flat_avg in got:
+    one_perf = O.filter_perfdata(O.AVG, O.DOUBLE_T, (rc, rv), (dc, dv))
+    one_perf_i = O.filter_perfdata(O.AVG, O.INT64_T, (rc, rv), (dc, (dv * 1000).astype(np.int64)))
+    for rank, res, ok, pd, plen, prank, status, exact, flat_avg, flat_perf in got:
+        pdf, plf, prf, pdi, pli, pri = flat_perf
+        assert plf == pli == K and prf == pri == one_perf[0] == -N
+        assert pdf.view(np.float64)[:K].tobytes() == one_perf[1].tobytes()
+        assert pdi.view(np.int64)[:K].tobytes() == one_perf_i[1].tobytes()
         assert ok == 1 and status == 0
         # the declared tree with the ranks as its last level
         assert res[:8].tobytes() == np.float64(want[0]).tobytes()

@@ -74,3 +74,28 @@ def test_two_contexts_on_two_streams(codec):
         assert np.array_equal(W.Codec.to_numpy(wire.arena)[:arena.size], arena)
         assert bool(ok.all()) and columns_equal(host_cols(fmt, dcols, n), ocols)
         assert cd.status() == 0
+
+
+def test_bound_calls_keep_their_buffers_alive(codec):
+    """A call bound once (Codec.bind_*) freezes raw device pointers; it must hold on to the tensors
+    they point into, so that a caller who drops its own references cannot free them under it."""
+    import gc
+    n = 4096
+    fmt = W.Format("%d")
+    vals = random_values(np.int32, n, 77)
+    wire = W.WireWave(codec.to_device(vals.view(np.uint8)), n, None, None, 4)
+    cols = codec.alloc_columns(fmt, n)
+    ok = codec.empty(n, torch.int32)
+    res, rok = codec.empty(16, torch.uint8), codec.empty(1, torch.int32)
+    call = codec.bind_decode_filter(fmt, wire, cols, ok, W.TFILTER_SUM, W.SHAPE_FLAT, res, rok)
+    col_ptr, res_ptr = cols[0].values.data_ptr(), res.data_ptr()
+    owned = {t.data_ptr() for t in call.owners if isinstance(t, torch.Tensor)}
+    assert {wire.arena.data_ptr(), col_ptr, ok.data_ptr(), res_ptr, rok.data_ptr()} <= owned
+    del wire, cols, ok, rok
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((n,), 0x55, dtype=torch.int32, device=codec.device) for _ in range(8)]    # would reuse freed blocks
+    call()
+    torch.cuda.synchronize()
+    assert int(res[:4].view(torch.int32).item()) == int(vals.sum(dtype=np.int32))
+    assert all(int(j[0].item()) == 0x55 for j in junk)

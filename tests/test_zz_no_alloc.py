@@ -87,3 +87,60 @@ def test_noalloc_filter_limits(codec):
                                          1 << 24, 0, res.data_ptr(), ok.data_ptr(), st) == 1
     torch.cuda.synchronize()
     assert int(ok.item()) == 1 and int(res[:4].cpu().numpy().view(np.int32)[0]) == 1 << 24
+
+
+@pytest.mark.parametrize("op,t,dt,shape,n", [
+    (W.TFILTER_SUM, W.DataType.INT32_T, np.int32, W.SHAPE_FLAT, 70_000),
+    (W.TFILTER_AVG, W.DataType.INT64_T, np.int64, W.SHAPE_FLAT, 70_000),
+    (W.TFILTER_SUM, W.DataType.FLOAT_T, np.float32, W.SHAPE_FLAT, 40_000),        # the device-wide float chain: three launches
+    (W.TFILTER_SUM, W.DataType.FLOAT_T, np.float32, W.SHAPE_FLAT, 9_000),         # the one-workgroup scan
+    (W.TFILTER_MIN, W.DataType.DOUBLE_T, np.float64, W.SHAPE_TREE, 5_000),
+])
+def test_noalloc_filter_under_graph_capture(codec, op, t, dt, shape, n):
+    """The property in the name: after one warm call (which resolves the built-in array's address) the
+    entry point is captured into a HIP graph -- a hipMalloc, hipFree or synchronisation inside the
+    captured region would fail the capture -- and the graph is replayed on new data; every replay
+    equals mrpdr_wave_filter (with a ctx) on the same data."""
+    lib = capi.load()
+    dt = np.dtype(dt)
+    dev = codec.device
+    vals = torch.zeros(n, dtype={np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
+                                 np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}[dt], device=dev)
+    cnts = torch.ones(n, dtype=torch.int32, device=dev)
+    res = torch.zeros(16, dtype=torch.uint8, device=dev)
+    ok = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def call(stream):
+        r = lib.mrpdr_wave_filter_noalloc(op, int(t), shape, vals.data_ptr(), dt.itemsize,
+                                          cnts.data_ptr() if op == W.TFILTER_AVG else None, 4, n, 0,
+                                          res.data_ptr(), ok.data_ptr(), stream)
+        assert r == 1, capi.last_error()
+
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        call(side.cuda_stream)                         # the warm call, outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            call(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for seed in (21, 22, 23):
+        if dt.kind == "f":
+            host = ((splitmix64(seed, n) % np.uint64(2_000_001)).astype(np.float64) / 1e3 - 900.0).astype(dt)
+        else:
+            host = (splitmix64(seed, n) % np.uint64(100000)).astype(dt)
+        hc = (splitmix64(seed + 5, n) % np.uint64(5) + np.uint64(1)).astype(np.int32)
+        vals.copy_(torch.from_numpy(host).to(dev))
+        cnts.copy_(torch.from_numpy(hc).to(dev))
+        res.fill_(0x5A)
+        ok.fill_(-7)
+        g.replay()
+        torch.cuda.synchronize()
+        want, wok = codec.filter_raw(op, t, vals.data_ptr(), dt.itemsize, cnts.data_ptr() if op == W.TFILTER_AVG else None,
+                                     4, n, 0, shape)
+        torch.cuda.synchronize()
+        assert int(ok.item()) == int(wok.item()) == 1
+        assert res.cpu().numpy().tobytes() == want.cpu().numpy().tobytes(), (op, int(t), n, seed)
+        if shape == W.SHAPE_FLAT:
+            ref = O.filter_flat(op, int(t), host, hc if op == W.TFILTER_AVG else None)
+            assert res.cpu().numpy()[:dt.itemsize].tobytes() == np.asarray(ref[0]).tobytes()
