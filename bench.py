@@ -430,8 +430,9 @@ def batched_small_waves_extra(dev):
 def perfdata_extra(codec):
     """Config 5, array variant: one GPU's shard of 131,072 '%ad %ad %alf' packets with 8 doubles
     each (the shape Stream::collect_PerfData emits), element-wise Avg
-      - as a declared three-level tree, 32 x 64 x 64 (nodes of 32 packets, of 64 nodes, one node over
-        the 64 results: three launches with chains of 32, 64 and 64 dependent steps);
+      - as a declared tree 16 x 32 x 32 x 8 (nodes of 16 packets, of 32 nodes, of 32 nodes, one node over
+        the 8 results: two launches, each folding two levels -- the nodes a workgroup holds are the
+        children of one node of the level above);
       - as the two-level tree of the earlier rounds (256 x 512), for comparison;
       - as ONE invocation over all packets (what the mirrors default to): doubles are a serial chain of
         131,072 roundings per element; int64 data of the same shape does not depend on the grouping and
@@ -447,8 +448,12 @@ def perfdata_extra(codec):
     idata = W.Column(ivals, data.counts, data.offs, n * k)
     res = {}
 
-    def tree3():
-        res["o"] = codec.filter_perfdata_levels(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, [32, 64, 0], out_cap=k)
+    outs3 = (codec.empty(k, torch.int64), codec.empty(1, torch.int64), codec.empty(1, torch.int32))
+    scr3 = codec.empty(1 << 22, torch.uint8)
+
+    def tree3():            # (a node that filters wave after wave keeps its output packet and scratch)
+        res["o"] = codec.filter_perfdata_levels(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, [16, 32, 32, 0], out_cap=k,
+                                                outputs=outs3, scratch=scr3)
 
     def tree2():
         res["o2"] = codec.filter_perfdata(W.TFILTER_AVG, W.DataType.DOUBLE_T, ranks, data, n, group=256, out_cap=k)
@@ -469,7 +474,7 @@ def perfdata_extra(codec):
     # (the int64 sums of this data do not wrap: the plain sum over all packets, divided once, truncating toward zero)
     sums = ivals.view(n, k).sum(dim=0)
     assert int(out_len.item()) == k and torch.equal(out[:k], torch.div(sums, n, rounding_mode="trunc"))
-    return {"c5b_perfdata_avg_us_per_wave": round(t3 * 1e6, 1), "c5b_perfdata_tree": "32 x 64 x 64",
+    return {"c5b_perfdata_avg_us_per_wave": round(t3 * 1e6, 1), "c5b_perfdata_tree": "16 x 32 x 32 x 8",
             "c5b_perfdata_avg_two_level_256_us_per_wave": round(t2 * 1e6, 1),
             "c5b_perfdata_avg_flat_us_per_wave": round(tf * 1e6, 1),
             "c5b_perfdata_avg_i64_flat_us_per_wave": round(ti * 1e6, 1)}

@@ -580,7 +580,9 @@ int32_t mrpdr_wave_perfdata(mrpdr_ctx *ctx, int32_t op, int32_t type,
  * MRNet processes with those fan-ins runs tfilter_PerfData at every node (AVG divides and re-weights
  * per node, the output of a node carries rank -total).  If the fan-ins leave more than one node, one
  * more level folds them all.  nlevels <= 8.  Short arrays (out_cap <= 64) put many nodes into one
- * workgroup: 131,072 packets as { 32, 64, 0 } are three launches with chains of 32, 64 and 64 steps.
+ * workgroup (256 / W of them, W = out_cap rounded up to a power of two, 8 at least), and a level whose
+ * fan-in is exactly that number is folded by the launch of the level below it: 131,072 packets of
+ * eight-element arrays as { 16, 32, 32, 0 } are two launches.
  * scratch: mrpdr_perfdata_levels_scratch_bytes(n, fanins, nlevels, out_cap) bytes, 16-byte aligned. */
 uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64_t *fanins, int32_t nlevels, uint64_t out_cap);
 int32_t mrpdr_wave_perfdata_levels(mrpdr_ctx *ctx, int32_t op, int32_t type,

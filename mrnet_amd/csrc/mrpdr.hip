@@ -1723,7 +1723,9 @@ static PerfPlan perf_plan(uint64_t n, const uint64_t *fanins, int nlevels)
 // what the nodes of one level take in the scratch: data, lens, offs, rank counts, rank offs, lasts, ranks
 static uint64_t perf_level_bytes(uint64_t nodes, uint64_t out_cap)
 {
-    return up16(nodes * out_cap * 8) + 5 * up16(nodes * 8) + up16(nodes * 4);
+    // (the data part ends in room for one workgroup's lanes: the level above reads a node's W elements
+    //  whatever its length, MRPDR_TPB of them at most)
+    return up16(nodes * out_cap * 8 + MRPDR_TPB * 8) + 5 * up16(nodes * 8) + up16(nodes * 4);
 }
 
 static uint64_t perf_plan_bytes(const PerfPlan &p, uint64_t out_cap)
@@ -1733,8 +1735,10 @@ static uint64_t perf_plan_bytes(const PerfPlan &p, uint64_t out_cap)
     return b;
 }
 
-// The order-free form of one invocation over integer data: raw nodes of 32 packets, of 64 nodes, then all.
-static const uint64_t PERF_FREE_FANINS[3] = { 32, 64, 0 };
+// The order-free form of one invocation over integer data: raw nodes of 16 packets, of 32 nodes, of 32, then all
+// (two launches for short arrays: k_perf_nodes folds two levels at a time).
+static const uint64_t PERF_FREE_FANINS[4] = { 16, 32, 32, 0 };
+#define PERF_FREE_LEVELS 4
 #define PERF_FREE_MIN 2048          // packets from which the raw tree is taken instead of the serial fold
 
 extern "C" uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64_t *fanins, int32_t nlevels, uint64_t out_cap)
@@ -1746,7 +1750,7 @@ extern "C" uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64
 extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
 {
     if (group == 0 || group >= n)           // one invocation: integer data may take the raw tree
-        return n >= PERF_FREE_MIN ? perf_plan_bytes(perf_plan(n, PERF_FREE_FANINS, 3), out_cap) : 0;
+        return n >= PERF_FREE_MIN ? perf_plan_bytes(perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS), out_cap) : 0;
     const uint64_t two[2] = { group, 0 };
     return perf_plan_bytes(perf_plan(n, two, 2), out_cap);
 }
@@ -1768,14 +1772,24 @@ static uint32_t perf_lanes(uint64_t out_cap)
     return w;
 }
 
-// One level.  Several nodes of short arrays: k_perf_nodes (many nodes per workgroup); one node, or long
-// arrays: k_perfdata (a node per workgroup row, its packets staged 256 at a time).
+// One level -- or two: several nodes of short arrays go to k_perf_nodes (many nodes per workgroup), which
+// folds the level above in the same launch when a workgroup's nodes are exactly one node's children;
+// one node, long nodes or long arrays go to k_perfdata (a node per workgroup row, its packets staged
+// 256 at a time).  Returns the number of levels done (0: failure).
+static bool perf_nodes_kernel(uint64_t nodes, uint64_t group, uint64_t out_cap)
+{
+    // (long nodes are better off with a workgroup each: k_perf_nodes takes a node's packets 32 at a
+    //  time, two to three dependent round trips per round; measured, nodes of 256: 69 against 39 us per wave)
+    return nodes > 1 && perf_lanes(out_cap) <= 64 && group <= 4 * PERF_CHUNK;
+}
+
 template <int OP, typename T>
-static int32_t launch_perf_level(const PerfIn &in, uint64_t nodes, const PerfOut &o, uint64_t out_cap, const PerfRaw &raw, hipStream_t st)
+static int32_t launch_perf_level(const PerfIn &in, uint64_t nodes, const PerfOut &o, uint64_t out_cap, const PerfRaw &raw,
+                                 uint64_t regular, bool fuse, bool raw_mid, hipStream_t st)
 {
     const uint32_t w = perf_lanes(out_cap);
-    if (nodes > 1 && w <= 64) {
-        PerfLevel a = { in, o, raw.in_lasts, raw.out_lasts, raw.out_packets, w, (uint32_t)nodes };
+    if (perf_nodes_kernel(nodes, in.group, out_cap)) {
+        PerfLevel a = { in, o, raw.in_lasts, raw.out_lasts, raw.out_packets, w, (uint32_t)nodes, regular, fuse ? 1u : 0u, raw_mid ? 1u : 0u };
         const uint32_t npb = MRPDR_TPB / w;
         k_perf_nodes<OP, T><<<dim3(1, (uint32_t)((nodes + npb - 1) / npb)), MRPDR_TPB, 0, st>>>(a);
         LAUNCHED("k_perf_nodes");
@@ -1796,11 +1810,19 @@ static int32_t run_perf_levels(mrpdr_ctx *c, PerfIn in, const PerfPlan &plan, bo
                                const PerfRaw &final_raw, uint8_t *scratch, hipStream_t st)
 {
     const uint64_t *in_lasts = nullptr;
+    uint64_t regular = 0;
     uint8_t *p = scratch;
+    const uint32_t npb = MRPDR_TPB / perf_lanes(out_cap);
     for (int l = 0; l < plan.levels; l++) {
-        const bool last_level = l + 1 == plan.levels;
-        const uint64_t nodes = plan.nodes[l];
+        uint64_t nodes = plan.nodes[l];
         in.group = plan.group[l];
+        // two levels in one launch: the workgroups of level l hold npb nodes each, and those are the
+        // children of one node of level l + 1
+        const bool fuse = l + 1 < plan.levels && perf_nodes_kernel(nodes, in.group, out_cap) &&
+                          (plan.group[l + 1] == npb || (nodes <= npb && plan.nodes[l + 1] == 1));
+        const int top = fuse ? l + 1 : l;           // the level whose nodes this launch leaves
+        const bool last_level = top + 1 == plan.levels;
+        const uint64_t out_nodes = plan.nodes[top];
         PerfOut o;
         PerfRaw r = { in_lasts, nullptr, nullptr, nullptr };
         PerfIn next = in;
@@ -1810,20 +1832,21 @@ static int32_t run_perf_levels(mrpdr_ctx *c, PerfIn in, const PerfPlan &plan, bo
             r.out_packets = final_raw.out_packets;
             if (plan.levels == 1) r.front = final_raw.front;
         } else {
-            void *d2 = p;                       p += up16(nodes * out_cap * 8);
-            uint64_t *lens2 = (uint64_t *)p;    p += up16(nodes * 8);
-            uint64_t *offs2 = (uint64_t *)p;    p += up16(nodes * 8);
-            uint64_t *rcnt2 = (uint64_t *)p;    p += up16(nodes * 8);
-            uint64_t *roff2 = (uint64_t *)p;    p += up16(nodes * 8);
-            uint64_t *lasts2 = (uint64_t *)p;   p += up16(nodes * 8);
-            int32_t *ranks2 = (int32_t *)p;     p += up16(nodes * 4);
+            void *d2 = p;                       p += up16(out_nodes * out_cap * 8 + MRPDR_TPB * 8);
+            uint64_t *lens2 = (uint64_t *)p;    p += up16(out_nodes * 8);
+            uint64_t *offs2 = (uint64_t *)p;    p += up16(out_nodes * 8);
+            uint64_t *rcnt2 = (uint64_t *)p;    p += up16(out_nodes * 8);
+            uint64_t *roff2 = (uint64_t *)p;    p += up16(out_nodes * 8);
+            uint64_t *lasts2 = (uint64_t *)p;   p += up16(out_nodes * 8);
+            int32_t *ranks2 = (int32_t *)p;     p += up16(out_nodes * 4);
             o = PerfOut{ d2, out_cap, lens2, offs2, ranks2, rcnt2, roff2, c->status };
             if (raw) r.out_lasts = lasts2;
-            next = PerfIn{ ranks2, rcnt2, roff2, d2, lens2, offs2, nodes, nodes };
-            in_lasts = raw ? lasts2 : nullptr;
+            next = PerfIn{ ranks2, rcnt2, roff2, d2, lens2, offs2, out_nodes, out_nodes };
         }
-        if (!launch_perf_level<OP, T>(in, nodes, o, out_cap, r, st)) return 0;
+        if (!launch_perf_level<OP, T>(in, nodes, o, out_cap, r, regular, fuse, raw, st)) return 0;
+        if (!last_level) { in_lasts = raw ? r.out_lasts : nullptr; regular = out_cap; }
         in = next;
+        l = top;
     }
     return 1;
 }
@@ -1921,7 +1944,7 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
         // One invocation.  Integer data does not depend on the grouping (raw nodes, one division at the
         // top): with room for the nodes it is computed as a tree of short chains; doubles, and callers
         // without scratch, fold the packets one after the other.
-        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, 3);
+        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS);
         const bool can = type != MRPDR_DOUBLE_T && n >= PERF_FREE_MIN && scratch && !((uintptr_t)scratch & 15u) &&
                          scratch_bytes >= perf_plan_bytes(free_plan, out_cap) && perf_lanes(out_cap) <= 64;
         if (can) return perf_run_plan(who, c, op, type, in, free_plan, true, out_cap, final, none, scratch, scratch_bytes, (hipStream_t)stream);
@@ -1962,7 +1985,7 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
     const uint64_t all[1] = { 0 };
     PerfPlan plan = perf_plan(n, all, 1);
     if (!chained && n >= PERF_FREE_MIN && perf_lanes(cap) <= 64) {
-        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, 3);
+        const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS);
         if (scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_plan_bytes(free_plan, cap)) plan = free_plan;
     }
     return perf_run_plan(who, c, op, type, in, plan, true, cap, final, raw, scratch, scratch_bytes, st);

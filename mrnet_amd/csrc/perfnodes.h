@@ -7,8 +7,9 @@
 // really carries (eight doubles per packet, src/Stream.C:1086-1110) and makes a node of 256 packets a
 // chain of 256 dependent steps.  Here a workgroup holds as many nodes as fit -- a node takes W lanes,
 // W the array bound rounded up to a power of two -- so that the levels of a tree are short chains
-// side by side: 131,072 packets as 32 x 64 x 64 are three launches whose chains are 32, 64 and 64
-// steps long.
+// side by side, and when the nodes of a workgroup are exactly the children of one node of the next
+// level (fan-in 32 for arrays of up to eight elements) that node is folded in the same launch:
+// 131,072 packets as 32 x 32 x 32 x 4 are two launches whose chains are 32 + 32 and 32 + 4 steps long.
 //
 // Two readings of "levels":
 //   * the declared tree: every node is a filter invocation of its own, as in a tree of processes --
@@ -24,8 +25,13 @@
 
 #include "filter.h"
 
+#ifdef MRPDR_TILE_STAMPS
+#define PERF_STAMP(k) do { if (threadIdx.x == 0 && g_tile_stamps) g_tile_stamps[(uint64_t)blockIdx.y * 8 + (k)] = wall_clock64(); } while (0)
+#else
+#define PERF_STAMP(k) do { } while (0)
+#endif
+
 #define PERF_CHUNK 32u          // packets of a node whose records are staged at a time
-#define PERF_BATCH 16           // packets whose values a lane has in flight together
 #define PERF_MIN_W 8u           // lanes per node at least: at most 32 nodes per workgroup
 
 // header of a raw node handed between GPUs (struct mrpdr_perf_state), followed by its accumulators
@@ -45,90 +51,198 @@ struct PerfLevel {
     uint32_t *out_packets;      // raw output of ONE node that is a state: its `packets` word (may be NULL)
     uint32_t W;                 // lanes per node: a power of two, PERF_MIN_W .. MRPDR_TPB
     uint32_t nodes;             // ceil(n / group)
+    uint64_t regular;           // the packets are nodes this library wrote itself: packet q has its data at
+                                // q * regular and its one rank at q (0: columns of any layout)
+    uint32_t fuse;              // the nodes of a workgroup are the children of ONE node of the level above,
+                                // which is folded here as well (out is that level's: node = workgroup)
+    uint32_t raw_mid;           // fuse: the nodes in between are raw
 };
 
 template <int OP, typename T>
 __global__ __launch_bounds__(MRPDR_TPB) void k_perf_nodes(PerfLevel a)
 {
-    // one record per staged packet: where its data lies, how long it is, what it weighs (0: no packet)
+    // per staged packet: where its data lies and how long it is (0: nothing to add) ...
     __shared__ uint4 s_rec[(MRPDR_TPB / PERF_MIN_W) * PERF_CHUNK];
+    // ... and what it weighs (0: no packet at all)
+    __shared__ int32_t s_nrank[(MRPDR_TPB / PERF_MIN_W) * PERF_CHUNK];
     const uint32_t t = threadIdx.x, W = a.W, npb = MRPDR_TPB / W;
-    const uint32_t ln = t / W;
+    const uint32_t ln = t / W, lu = t % W;
     const uint64_t node0 = (uint64_t)blockIdx.y * npb, node = node0 + ln;
-    const uint64_t u = (uint64_t)blockIdx.x * W + (t % W);
+    const uint64_t u = (uint64_t)blockIdx.x * W + lu;
     const bool raw_in = a.in_lasts != nullptr, raw_out = a.out_lasts != nullptr;
     const uint64_t group = a.in.group, n = a.in.n;
     const uint64_t i0 = node * group;
     const uint64_t i1 = node < a.nodes ? (i0 + group < n ? i0 + group : n) : i0;
     const T *data = reinterpret_cast<const T *>(a.in.data_vals);
     // (a load that is not wanted reads this instead: an address that is there whatever the wave holds)
-    const T *idle = reinterpret_cast<const T *>(a.in.data_counts);
+    const uint64_t *idle = a.in.data_counts;
     T acc;
     __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
     uint32_t total = 0;
     uint64_t longest = 0, last = 0;
-    const uint32_t nrec = npb * PERF_CHUNK;
+    // A node's records are fetched by the node's own lanes: lane lu takes packets lu, lu + W, ... of the
+    // chunk (W <= 32: PERF_CHUNK / W each; wider nodes: the first 32 lanes one each).
+    PERF_STAMP(0);
+    constexpr int RMAX = PERF_CHUNK / PERF_MIN_W;
+    const uint32_t per_lane = W < PERF_CHUNK ? PERF_CHUNK / W : 1u;
+    uint4 *rec = s_rec + ln * PERF_CHUNK;
+    int32_t *nrk = s_nrank + ln * PERF_CHUNK;
     for (uint64_t c = 0; c < group; c += PERF_CHUNK) {
-        __syncthreads();
-        // records of this chunk, all nodes of the workgroup: the four loads of a packet are independent
-        // (and unconditional: a record past its node's end re-reads packet n - 1), the rank is one more trip
-        for (uint32_t r0 = 0; r0 < nrec; r0 += MRPDR_TPB) {
-            const uint32_t r = r0 + t;
-            const uint32_t rn = r / PERF_CHUNK, rj = r % PERF_CHUNK;
-            const uint64_t gn = node0 + rn;
-            const uint64_t pi = gn * group + c + rj;
-            const uint64_t pend = gn < a.nodes ? (gn * group + group < n ? gn * group + group : n) : 0;
-            const bool have = r < nrec && c + rj < group && pi < pend;
-            const uint64_t q = have ? pi : n - 1;
-            const uint64_t len = a.in.data_counts[q], off = a.in.data_offs[q];
-            const uint64_t rc = a.in.rank_counts[q], ro = a.in.rank_offs[q];
-            int32_t rank = 0;
-            if (have && len && rc) rank = a.in.rank_vals[ro];
-            const int32_t nrank = rank < 0 ? 0 - rank : 1;
-            if (r < nrec) s_rec[r] = have ? make_uint4((uint32_t)off, (uint32_t)(off >> 32), (uint32_t)len, (uint32_t)nrank)
-                                          : make_uint4(0u, 0u, 0u, 0u);
-        }
-        __syncthreads();
         const uint64_t at = i0 + c;
         const uint32_t m = at < i1 ? (uint32_t)(i1 - at < PERF_CHUNK ? i1 - at : PERF_CHUNK) : 0u;
-        const uint4 *rec = s_rec + ln * PERF_CHUNK;
-        for (uint32_t j0 = 0; j0 < m; j0 += PERF_BATCH) {
-            uint4 r[PERF_BATCH];
-            T x[PERF_BATCH];
+        __syncthreads();                        // the chunk before has been folded
+        uint64_t len[RMAX], off[RMAX], rc[RMAX], ro[RMAX];
+        int32_t rank[RMAX];
+        T x[PERF_CHUNK];
+        if (a.regular) {
+            // nodes of a level below, laid out by this library: everything is one round trip -- lengths,
+            // ranks and (whatever the lengths will say: a node's room is always there) the values
 #pragma unroll
-            for (int k = 0; k < PERF_BATCH; k++) {
-                r[k] = rec[j0 + k < m ? j0 + k : m - 1];
-                const bool wanted = j0 + k < m && u < r[k].z;
-                const T *p = wanted ? data + (((uint64_t)r[k].y << 32) | r[k].x) + u : idle;
-                x[k] = *p;
+            for (int k = 0; k < RMAX; k++) {
+                const uint32_t j = lu + (uint32_t)k * W;
+                const bool mine = (uint32_t)k < per_lane && j < m;
+                const uint64_t q = mine ? at + j : n - 1;
+                len[k] = a.in.data_counts[q]; rank[k] = a.in.rank_vals[q];
+                off[k] = q * a.regular; rc[k] = 1; ro[k] = q;
             }
 #pragma unroll
-            for (int k = 0; k < PERF_BATCH; k++) {
-                if (j0 + k < m) {
-                    const uint32_t len = r[k].z;
-                    const int32_t nrank = (int32_t)r[k].w;
-                    total += len ? (uint32_t)nrank : 0u;
-                    longest = len > longest ? len : longest;
-                    last = len;
-                    if (u < len) acc = perf_fold<OP, T>(acc, x[k], raw_in ? 1 : nrank);
-                }
+            for (uint32_t j = 0; j < PERF_CHUNK; j++) {
+                const uint64_t q = j < m ? at + j : (m ? at + m - 1 : n - 1);
+                x[j] = data[q * a.regular + u];
+            }
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) {
+                const uint32_t j = lu + (uint32_t)k * W;
+                const bool mine = (uint32_t)k < per_lane && j < m;
+                if ((uint32_t)k < per_lane && j < PERF_CHUNK)
+                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), (uint32_t)len[k], 1u) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        } else {
+            // round trip one: lengths, places, rank counts (unconditional: a record past the node's end
+            // re-reads packet n - 1)
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) {
+                const uint32_t j = lu + (uint32_t)k * W;
+                const bool mine = (uint32_t)k < per_lane && j < m;
+                const uint64_t q = mine ? at + j : n - 1;
+                len[k] = a.in.data_counts[q]; off[k] = a.in.data_offs[q];
+                rc[k] = a.in.rank_counts[q]; ro[k] = a.in.rank_offs[q];
+            }
+            // round trip two, first half: the ranks (asked for now, looked at behind the data loads)
+#pragma unroll
+            for (int k = 0; k < RMAX; k++) {
+                const uint32_t j = lu + (uint32_t)k * W;
+                const bool mine = (uint32_t)k < per_lane && j < m;
+                const int32_t *p = (mine && len[k] && rc[k]) ? a.in.rank_vals + ro[k] : reinterpret_cast<const int32_t *>(idle);
+                rank[k] = *p;
+                if ((uint32_t)k < per_lane && j < PERF_CHUNK)
+                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), (uint32_t)len[k], 1u) : make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            PERF_STAMP(1);
+            // round trip two, second half: every value of the chunk this lane will add.  (All records out of
+            // LDS first, then all loads: read and load by turns, every load waited for its record's trip to LDS.)
+            uint4 r[PERF_CHUNK];
+#pragma unroll
+            for (uint32_t j = 0; j < PERF_CHUNK; j++) r[j] = rec[j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (uint32_t j = 0; j < PERF_CHUNK; j++) {
+                const bool wanted = j < m && u < r[j].z;
+                const T *p = wanted ? data + (((uint64_t)r[j].y << 32) | r[j].x) + u : reinterpret_cast<const T *>(idle);
+                x[j] = *p;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RMAX; k++) {
+            const uint32_t j = lu + (uint32_t)k * W;
+            const bool mine = (uint32_t)k < per_lane && j < m;
+            const int32_t r = (mine && len[k] && rc[k]) ? rank[k] : 0;
+            if ((uint32_t)k < per_lane && j < PERF_CHUNK) nrk[j] = mine ? (r < 0 ? 0 - r : 1) : 0;
+        }
+        __syncthreads();
+        PERF_STAMP(2);
+        uint32_t ls[PERF_CHUNK];
+        int32_t ws[PERF_CHUNK];
+#pragma unroll
+        for (uint32_t j = 0; j < PERF_CHUNK; j++) { ls[j] = rec[j].z; ws[j] = nrk[j]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t j = 0; j < PERF_CHUNK; j++) {
+            if (j < m) {
+                const uint32_t l = ls[j];
+                const int32_t nrank = ws[j];
+                total += l ? (uint32_t)nrank : 0u;
+                longest = l > longest ? l : longest;
+                last = l;
+                if (u < l) acc = perf_fold<OP, T>(acc, x[j], raw_in ? 1 : nrank);
             }
         }
     }
-    if (node >= a.nodes) return;
-    if (raw_in && i1 > i0) last = a.in_lasts[i1 - 1];
+#ifdef MRPDR_TILE_STAMPS
+    if (__builtin_amdgcn_readfirstlane((int)(acc != acc)) == 12345) return;      // (the fold's result is needed in front of the stamp)
+#endif
+    PERF_STAMP(3);
+    const bool valid = node < a.nodes;
+    if (raw_in && valid && i1 > i0) last = a.in_lasts[i1 - 1];
+    uint64_t at_node = node;
+    if (a.fuse) {
+        // The workgroup's nodes are finished as outputs of their own level (divided unless raw), parked
+        // in LDS, and the lanes of its first node fold them in order as the ONE node of the level above.
+        __shared__ T s_acc2[MRPDR_TPB];
+        __shared__ uint32_t s_len2[MRPDR_TPB / PERF_MIN_W], s_tot2[MRPDR_TPB / PERF_MIN_W];
+        __shared__ uint64_t s_last2[MRPDR_TPB / PERF_MIN_W];
+        const bool raw1 = a.raw_mid != 0;
+        if (valid && !raw1 && OP == MRPDR_AVG && last && u < last) acc = acc / (T)total;
+        if (longest > a.out.stride) {
+            if (u == 0) atomicOr(a.out.status, 1u);
+            longest = 0;
+        }
+        s_acc2[t] = acc;
+        if (lu == 0) { s_len2[ln] = valid ? (uint32_t)longest : 0u; s_tot2[ln] = total; s_last2[ln] = last; }
+        __syncthreads();
+        if (ln != 0) return;
+        const uint32_t children = (uint32_t)(a.nodes - node0 < npb ? a.nodes - node0 : npb);
+        __builtin_memset(&acc, OP == MRPDR_MIN ? 0xFF : 0, sizeof acc);
+        total = 0; longest = 0; last = 0;
+        // (everything out of LDS first -- a workgroup holds 32 nodes at most -- then the chain)
+        constexpr uint32_t CMAX = MRPDR_TPB / PERF_MIN_W;
+        uint32_t cl[CMAX], ct[CMAX];
+        uint64_t ck[CMAX];
+        T cx[CMAX];
+#pragma unroll
+        for (uint32_t j = 0; j < CMAX; j++) {
+            const uint32_t jj = j < children ? j : 0u;
+            cl[j] = s_len2[jj]; ct[j] = s_tot2[jj]; ck[j] = s_last2[jj];
+            cx[j] = s_acc2[jj * W + lu];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (uint32_t j = 0; j < CMAX; j++) {
+            if (j < children) {
+                const uint32_t l = cl[j];
+                const int32_t nrank = (int32_t)ct[j];           // the child's rank is -total: it weighs `total` ranks
+                total += l ? (uint32_t)nrank : 0u;
+                longest = l > longest ? l : longest;
+                last = raw1 ? ck[j] : l;
+                if (u < l) acc = perf_fold<OP, T>(acc, cx[j], raw1 ? 1 : nrank);
+            }
+        }
+        at_node = blockIdx.y;
+        PERF_STAMP(4);
+    } else if (!valid) return;
     if (!raw_out && OP == MRPDR_AVG && last && u < last) acc = acc / (T)total;
     if (longest > a.out.stride) {                   // the result does not fit: say so, write nothing
         if (u == 0) atomicOr(a.out.status, 1u);
         longest = 0;
     }
-    if (u < longest) reinterpret_cast<T *>(a.out.data)[node * a.out.stride + u] = acc;
+    if (u < longest) reinterpret_cast<T *>(a.out.data)[at_node * a.out.stride + u] = acc;
     if (u == 0) {
-        a.out.lens[node] = longest;
-        a.out.ranks[node] = 0 - (int32_t)total;
-        if (a.out.offs) a.out.offs[node] = node * a.out.stride;
-        if (a.out.rank_counts) { a.out.rank_counts[node] = 1; a.out.rank_offs[node] = node; }
-        if (raw_out) a.out_lasts[node] = last;
+        a.out.lens[at_node] = longest;
+        a.out.ranks[at_node] = 0 - (int32_t)total;
+        if (a.out.offs) a.out.offs[at_node] = at_node * a.out.stride;
+        if (a.out.rank_counts) { a.out.rank_counts[at_node] = 1; a.out.rank_offs[at_node] = at_node; }
+        if (raw_out) a.out_lasts[at_node] = last;
         if (a.out_packets) *a.out_packets = 1u;
     }
 }

@@ -694,16 +694,20 @@ class Codec:
         _check(r, "mrpdr_wave_perfdata")
         return out, out_len, out_rank
 
-    def filter_perfdata_levels(self, op, dtype, ranks, data, n, fanins, out_cap=None):
+    def filter_perfdata_levels(self, op, dtype, ranks, data, n, fanins, out_cap=None, outputs=None, scratch=None):
         """tfilter_PerfData as a declared tree: level l folds groups of fanins[l] packets of the level
-        below (0 = all), one filter invocation per group.  Returns (out_data, out_len, out_rank)."""
+        below (0 = all), one filter invocation per group.  Returns (out_data, out_len, out_rank);
+        outputs / scratch: those three tensors and the scratch of an earlier call, for a caller that
+        filters wave after wave."""
         if out_cap is None:
             out_cap = int(data.counts.max().item()) if n else 0
         fan = (C.c_uint64 * len(fanins))(*[int(f) for f in fanins])
-        out = self.empty(max(out_cap, 1), torch.int64)
-        out_len, out_rank = self.empty(1, torch.int64), self.empty(1, torch.int32)
         need = int(self._lib.mrpdr_perfdata_levels_scratch_bytes(n, fan, len(fanins), out_cap))
-        scratch = self.empty(max(need, 16), torch.uint8) if need else None
+        if outputs is None:
+            outputs = (self.empty(max(out_cap, 1), torch.int64), self.empty(1, torch.int64), self.empty(1, torch.int32))
+        out, out_len, out_rank = outputs
+        if scratch is None or scratch.numel() < need:
+            scratch = self.empty(max(need, 16), torch.uint8) if need else None
         a, b = ranks.c_struct(), data.c_struct()
         _check(self._lib.mrpdr_wave_perfdata_levels(self.handle, op, int(dtype), C.byref(a), C.byref(b), n, fan, len(fanins),
                                                     _ptr(out), out_cap, _ptr(out_len), _ptr(out_rank), _ptr(scratch), need,

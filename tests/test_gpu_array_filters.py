@@ -320,6 +320,9 @@ def _perf_result(t, out, out_len, out_rank):
 @pytest.mark.parametrize("t", [O.UINT64_T, O.INT64_T, O.DOUBLE_T])
 @pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG])
 @pytest.mark.parametrize("n,kmax,same,fanins", [(5000, 8, True, [32, 64, 0]), (5000, 8, False, [7, 5, 3]),
+                                                (131072, 8, True, [32, 32, 32, 0]), (40001, 8, False, [32, 32, 32, 0]),
+                                                (9000, 5, False, [32, 32, 0]), (2000, 13, False, [16, 16, 0]),
+                                                (1500, 30, False, [8, 8, 8, 8]), (33, 8, False, [32, 32, 0]),
                                                 (40000, 8, False, [32, 64, 0]), (3000, 40, False, [16, 0]),
                                                 (3000, 100, False, [16, 4, 0]), (70, 8, True, [32, 64, 0]),
                                                 (1, 8, True, [32, 0])])
