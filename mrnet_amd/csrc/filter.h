@@ -687,6 +687,7 @@ struct PerfRaw {
     uint64_t *out_lasts;
     const uint8_t *front;             // struct mrpdr_perf_state + accumulators, or NULL
     uint32_t *out_packets;            // where a state's `packets` word goes, or NULL
+    const uint64_t *unless;           // the launch leaves at once when *unless != 0 (another path has the wave), or NULL
 };
 struct PerfFront { uint64_t longest, last; int32_t rank; uint32_t packets; uint64_t reserved; };
 
@@ -699,7 +700,7 @@ template <int OP, typename T> __device__ __forceinline__ T perf_fold(T acc, T x,
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out, PerfRaw raw = PerfRaw{ nullptr, nullptr, nullptr, nullptr })
+__global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out, PerfRaw raw = PerfRaw{ nullptr, nullptr, nullptr, nullptr, nullptr })
 {
     // The packets of the node are taken in tiles of 256: their lengths, offsets and rank counts
     // go to LDS (one packet per lane), and when the tile's data -- one contiguous run of the
@@ -711,6 +712,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perfdata(PerfIn in, PerfOut out, 
     __shared__ T s_data[PERF_STAGE_ELEMS];
     __shared__ uint32_t s_total;
     __shared__ unsigned long long s_longest;
+    if (raw.unless && *raw.unless) return;
     const uint64_t g = blockIdx.y;
     const uint32_t t = threadIdx.x;
     const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + t;

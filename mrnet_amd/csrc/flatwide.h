@@ -143,7 +143,7 @@ __device__ __forceinline__ double wide_block_sum(double v, double *s_part)
 
 // ---- pass 1: an ordinary sum of every chunk (double, any order) and its AVG count --------------------
 template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_sums(FilterIn in, void *ws_base, uint64_t nc)
+__device__ __forceinline__ void wide_sums_body(const FilterIn &in, void *ws_base, uint64_t nc)
 {
     __shared__ double s_part[WIDE_TPB / 64];
     __shared__ int32_t s_cnt;
@@ -205,7 +205,13 @@ template <typename T> __device__ __forceinline__ bool wide_inside(typename Grid<
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_base, uint64_t nc, FilterLink link = FilterLink{ nullptr, nullptr })
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_sums(FilterIn in, void *ws_base, uint64_t nc)
+{
+    wide_sums_body<OP, T>(in, ws_base, nc);
+}
+
+template <int OP, typename T>
+__device__ __forceinline__ void wide_maps_body(const FilterIn &in, void *ws_base, uint64_t nc, const FilterLink &link)
 {
     typedef Grid<T> G;
     typedef typename G::S S;
@@ -354,6 +360,12 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_ba
     }
     if ((head.bad & WIDE_CHUNK_BITS) == WIDE_CHUNK_BITS) head.bad |= WIDE_HINT;
     if (t == 0) ws.heads[c] = head;
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_maps(FilterIn in, void *ws_base, uint64_t nc, FilterLink link = FilterLink{ nullptr, nullptr })
+{
+    wide_maps_body<OP, T>(in, ws_base, nc, link);
 }
 
 // ---- pass 3: the chunks in order ---------------------------------------------------------------------
@@ -530,8 +542,8 @@ __device__ __forceinline__ uint32_t wide_next_hint(uint64_t h0, uint64_t h1, uin
 }
 
 template <int OP, typename T>
-__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok,
-                                                        FilterLink link = FilterLink{ nullptr, nullptr })
+__device__ __forceinline__ void wide_walk_body(const FilterIn &in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok,
+                                               const FilterLink &link)
 {
     typedef Grid<T> G;
     typedef typename G::S S;
@@ -684,4 +696,51 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
         __syncthreads();
     }
     if (t == 0) chain_finish<OP, T>(link, in.n, acc, s_cnt, result, result_ok);
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok,
+                                                        FilterLink link = FilterLink{ nullptr, nullptr })
+{
+    wide_walk_body<OP, T>(in, ws_base, nc, result, result_ok, link);
+}
+
+// ---- several columns at once ---------------------------------------------------------------------------
+// The same three passes over strided columns side by side (blockIdx.y picks the column).  Used for
+// performance-data packets whose arrays all have one length k and lie end to end: element y of every
+// packet is a column (values at base + (first + y) * sizeof(T), k * sizeof(T) apart), and the elements'
+// chains run next to each other, one walking workgroup each.  What the host does not know is read on the
+// device: shape[0] = 1 if the wave has that form (0 switches the launch off), shape[1] = k, shape[2] =
+// first (the element index of packet 0's array in the values column).  Column y has its summaries at
+// ws_base + y * ws_stride and its result at result + 16 y.
+struct WideMulti { const uint64_t *shape; uint64_t ws_stride; };
+
+template <typename T> __device__ __forceinline__ bool wide_multi_column(const WideMulti &m, FilterIn &in)
+{
+    const uint64_t on = m.shape[0], k = m.shape[1], first = m.shape[2];
+    if (!on || blockIdx.y >= k) return false;
+    in.values += (first + blockIdx.y) * sizeof(T);
+    in.value_stride = k * sizeof(T);
+    return true;
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_sums_multi(FilterIn in, void *ws_base, uint64_t nc, WideMulti m)
+{
+    if (!wide_multi_column<T>(m, in)) return;
+    wide_sums_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc);
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_maps_multi(FilterIn in, void *ws_base, uint64_t nc, WideMulti m)
+{
+    if (!wide_multi_column<T>(m, in)) return;
+    wide_maps_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, FilterLink{ nullptr, nullptr });
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(WIDE_TPB) void k_wide_walk_multi(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok, WideMulti m)
+{
+    if (!wide_multi_column<T>(m, in)) return;
+    wide_walk_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, result + 16u * blockIdx.y, result_ok + blockIdx.y, FilterLink{ nullptr, nullptr });
 }

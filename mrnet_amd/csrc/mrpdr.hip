@@ -1747,10 +1747,26 @@ extern "C" uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64
     return perf_plan_bytes(perf_plan(n, fanins, nlevels), out_cap);
 }
 
+// One invocation over doubles whose arrays all have one length: the elements as strided columns through the
+// device-wide exact fold (perfnodes.h, k_perf_shape).  Room: shape words, the weights, results, summaries.
+#define PERF_COLUMNS_MIN FLAT_WIDE_MIN_DOUBLE       // packets from which the strided fold is tried
+#define PERF_COLUMNS_MAX_CAP 64u                    // elements per packet at most (one walking workgroup each)
+static uint64_t perf_columns_ws_stride(uint64_t n)
+{
+    return up16(WideWs<double>::bytes((n + WIDE_CHUNK - 1) / WIDE_CHUNK));
+}
+static uint64_t perf_columns_bytes(uint64_t n, uint64_t out_cap)
+{
+    return 64 + up16(4 * n) + up16(16 * out_cap) + up16(4 * out_cap) + out_cap * perf_columns_ws_stride(n);
+}
+
 extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
 {
-    if (group == 0 || group >= n)           // one invocation: integer data may take the raw tree
-        return n >= PERF_FREE_MIN ? perf_plan_bytes(perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS), out_cap) : 0;
+    if (group == 0 || group >= n) {         // one invocation: integer data may take the raw tree, regular doubles the strided fold
+        const uint64_t a = n >= PERF_FREE_MIN ? perf_plan_bytes(perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS), out_cap) : 0;
+        const uint64_t b = (n >= PERF_COLUMNS_MIN && out_cap && out_cap <= PERF_COLUMNS_MAX_CAP) ? perf_columns_bytes(n, out_cap) : 0;
+        return a > b ? a : b;
+    }
     const uint64_t two[2] = { group, 0 };
     return perf_plan_bytes(perf_plan(n, two, 2), out_cap);
 }
@@ -1824,13 +1840,13 @@ static int32_t run_perf_levels(mrpdr_ctx *c, PerfIn in, const PerfPlan &plan, bo
         const bool last_level = top + 1 == plan.levels;
         const uint64_t out_nodes = plan.nodes[top];
         PerfOut o;
-        PerfRaw r = { in_lasts, nullptr, nullptr, nullptr };
+        PerfRaw r = { in_lasts, nullptr, nullptr, nullptr, nullptr };
         PerfIn next = in;
         if (last_level) {
             o = final;
             r.out_lasts = final_raw.out_lasts;
             r.out_packets = final_raw.out_packets;
-            if (plan.levels == 1) r.front = final_raw.front;
+            if (plan.levels == 1) { r.front = final_raw.front; r.unless = final_raw.unless; }
         } else {
             void *d2 = p;                       p += up16(out_nodes * out_cap * 8 + MRPDR_TPB * 8);
             uint64_t *lens2 = (uint64_t *)p;    p += up16(out_nodes * 8);
@@ -1920,7 +1936,7 @@ extern "C" int32_t mrpdr_wave_perfdata_levels(mrpdr_ctx *c, int32_t op, int32_t 
     if (perf_lanes(out_cap) > 64)
         for (int l = 0; l < plan.levels; l++)
             if (plan.nodes[l] > 65535) return fail("%s: more than 65535 nodes of long arrays on one level", who);
-    return perf_run_plan(who, c, op, type, in, plan, false, out_cap, final, PerfRaw{ nullptr, nullptr, nullptr, nullptr }, scratch,
+    return perf_run_plan(who, c, op, type, in, plan, false, out_cap, final, PerfRaw{ nullptr, nullptr, nullptr, nullptr, nullptr }, scratch,
                          scratch_bytes, (hipStream_t)stream);
 }
 
@@ -1939,7 +1955,7 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
         return fail("%s: type %d is not a performance-data type", who, type);
     PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts, data->offs, n, n };
     PerfOut final = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
-    const PerfRaw none = { nullptr, nullptr, nullptr, nullptr };
+    const PerfRaw none = { nullptr, nullptr, nullptr, nullptr, nullptr };
     if (group == 0 || group >= n) {
         // One invocation.  Integer data does not depend on the grouping (raw nodes, one division at the
         // top): with room for the nodes it is computed as a tree of short chains; doubles, and callers
@@ -1949,7 +1965,48 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
                          scratch_bytes >= perf_plan_bytes(free_plan, out_cap) && perf_lanes(out_cap) <= 64;
         if (can) return perf_run_plan(who, c, op, type, in, free_plan, true, out_cap, final, none, scratch, scratch_bytes, (hipStream_t)stream);
         const uint64_t all[1] = { 0 };
-        return perf_run_plan(who, c, op, type, in, perf_plan(n, all, 1), false, out_cap, final, none, nullptr, 0, (hipStream_t)stream);
+        const PerfPlan serial = perf_plan(n, all, 1);
+        hipStream_t st = (hipStream_t)stream;
+        // Doubles, SUM / AVG: if every packet carries the same number of elements, end to end, the elements
+        // are strided columns and their chains of roundings are taken by the device-wide exact fold, side
+        // by side; the device finds out (k_perf_shape), and the serial fold below runs only if not.
+        if (type == MRPDR_DOUBLE_T && (op == MRPDR_SUM || op == MRPDR_AVG) && n >= PERF_COLUMNS_MIN && out_cap &&
+            out_cap <= PERF_COLUMNS_MAX_CAP && scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, out_cap)) {
+            uint8_t *p = (uint8_t *)scratch;
+            uint64_t *shape = (uint64_t *)p;                    // [0] regular, [1] k, [2] first, [3] total ranks
+            uint32_t *irregular = (uint32_t *)(p + 32);         p += 64;
+            int32_t *nranks = (int32_t *)p;                     p += up16(4 * n);
+            uint8_t *results = p;                               p += up16(16 * out_cap);
+            int32_t *oks = (int32_t *)p;                        p += up16(4 * out_cap);
+            void *ws = p;
+            const uint64_t nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
+            HIP_OK(hipMemsetAsync(scratch, 0, 64, st));
+            k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, out_cap, shape, nranks, irregular);
+            LAUNCHED("k_perf_shape");
+            k_perf_shape_verdict<<<1, 1, 0, st>>>(shape, irregular);
+            LAUNCHED("k_perf_shape_verdict");
+            FilterIn fin = { (const uint8_t *)data->values, 0, (const uint8_t *)nranks, 4, n, 0, nullptr };
+            const WideMulti m = { shape, perf_columns_ws_stride(n) };
+            const dim3 wide((uint32_t)nc, (uint32_t)out_cap), one(1, (uint32_t)out_cap);
+            if (op == MRPDR_SUM) {
+                k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+                k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+                k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
+                LAUNCHED("k_wide_*_multi");
+                k_perf_from_columns<MRPDR_SUM><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
+            } else {
+                k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+                k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+                k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
+                LAUNCHED("k_wide_*_multi");
+                k_perf_from_columns<MRPDR_AVG><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
+            }
+            LAUNCHED("k_perf_from_columns");
+            PerfRaw unless_regular = none;
+            unless_regular.unless = shape;
+            return perf_run_plan(who, c, op, type, in, serial, false, out_cap, final, unless_regular, nullptr, 0, st);
+        }
+        return perf_run_plan(who, c, op, type, in, serial, false, out_cap, final, none, nullptr, 0, st);
     }
     if ((n + group - 1) / group > 65535 && perf_lanes(out_cap) > 64) return fail("%s: more than 65535 first-level nodes", who);
     const uint64_t two[2] = { group, 0 };
@@ -1981,7 +2038,7 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
     HIP_OK(hipMemsetAsync(state, 0, sizeof(PerfState), st));
     PerfIn in = { (const int32_t *)ranks->values, ranks->counts, ranks->offs, data->values, data->counts, data->offs, n, n };
     PerfOut final = { sp + sizeof(PerfState), cap, &h->longest, nullptr, &h->rank, nullptr, nullptr, c->status };
-    PerfRaw raw = { nullptr, &h->last, (const uint8_t *)front, &h->packets };
+    PerfRaw raw = { nullptr, &h->last, (const uint8_t *)front, &h->packets, nullptr };
     const uint64_t all[1] = { 0 };
     PerfPlan plan = perf_plan(n, all, 1);
     if (!chained && n >= PERF_FREE_MIN && perf_lanes(cap) <= 64) {

@@ -279,3 +279,57 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_combine(const uint8_t *state
         out.ranks[0] = 0 - (int32_t)total;
     }
 }
+
+// ---- one invocation over doubles whose arrays all have one length -------------------------------------
+// Doubles round at every addition, so one invocation of SUM / AVG is a chain per element -- 131,072
+// dependent steps for a GPU's shard.  The exact chain has a fast form (flatwide.h), and when every
+// packet carries the same number of elements, end to end in the values column (what a stream of one
+// metric's performance data looks like), element u of all packets IS a strided column: the elements'
+// chains are taken by the device-wide fold side by side.  Whether the wave has that form is found out
+// on the device: k_perf_shape checks it and leaves the weights (nrank) as an int32 column; the strided
+// fold runs if it has, the serial k_perfdata if it has not (each looks at shape[0] and leaves at once
+// when it is not its turn).
+//   shape[0] regular (1 / 0)   shape[1] k   shape[2] first element   shape[3] total ranks
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_shape(PerfIn in, uint64_t cap, uint64_t *shape, int32_t *nranks, uint32_t *irregular)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint64_t k = in.data_counts[0], first = in.data_offs[0];
+    bool bad = k == 0 || k > cap;
+    uint32_t nrank = 0;
+    if (i < in.n) {
+        bad = bad || in.data_counts[i] != k || in.data_offs[i] != first + i * k;
+        int32_t rank = 0;
+        if (in.rank_counts[i]) rank = in.rank_vals[in.rank_offs[i]];
+        nrank = (uint32_t)(rank < 0 ? 0 - rank : 1);
+        nranks[i] = (int32_t)nrank;
+    }
+    // the rank total and the verdict: wavefront first, then one atomic each
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) nrank += __shfl_xor(nrank, d, 64);
+    const bool any_bad = __ballot(bad) != 0;
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(&shape[3]), (unsigned long long)nrank);
+        if (any_bad) atomicOr(irregular, 1u);
+    }
+    if (i == 0) { shape[1] = k; shape[2] = first; }
+}
+
+// (a launch of its own: every workgroup of k_perf_shape has to have spoken)
+__global__ void k_perf_shape_verdict(uint64_t *shape, const uint32_t *irregular)
+{
+    shape[0] = *irregular ? 0u : 1u;
+}
+
+// the k results of the strided fold into the output packet
+template <int OP>
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_from_columns(const uint64_t *shape, const uint8_t *results, PerfOut out)
+{
+    if (!shape[0]) return;
+    const uint64_t k = shape[1], u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (k > out.stride) {
+        if (u == 0) { atomicOr(out.status, 1u); out.lens[0] = 0; out.ranks[0] = 0 - (int32_t)(uint32_t)shape[3]; }
+        return;
+    }
+    if (u < k) reinterpret_cast<uint64_t *>(out.data)[u] = *reinterpret_cast<const uint64_t *>(results + 16 * u);
+    if (u == 0) { out.lens[0] = k; out.ranks[0] = 0 - (int32_t)(uint32_t)shape[3]; }
+}

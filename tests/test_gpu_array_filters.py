@@ -408,3 +408,41 @@ def test_perfdata_in_ranges_equals_one_invocation(codec, t, op):
             assert got[0] == ref[0] and got[1].size == ref[1].size, (n, edges, got, ref)
             assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, edges, got[1][:4], ref[1][:4])
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN])
+@pytest.mark.parametrize("n,k", [(8192, 8), (20001, 3), (131072, 8), (40000, 64), (9000, 1)])
+def test_perfdata_double_one_invocation_regular_waves(codec, op, n, k):
+    """One invocation over doubles is a chain of roundings per element.  When every packet carries the
+    same number of elements, end to end (one metric's stream), the elements are strided columns and the
+    device-wide exact fold takes their chains side by side: the bits of the oracle's serial loop over all
+    packets.  Checked on regular waves (aggregated ranks as weights), on the same wave with one packet
+    made shorter or empty (the device finds out and the serial fold runs), and with a first array that
+    does not start the values column."""
+    t = O.DOUBLE_T
+    for variant in ("regular", "one_short", "one_empty", "offset"):
+        ranks, data = perf_wave(n, t, seed=n + k + op, kmax=k, same_len=True, aggregated=True)
+        lens, vals = data
+        if variant == "one_short" and k > 1:
+            lens = lens.copy()
+            at = int(lens[: n // 2].sum())
+            lens[n // 2] = k - 1
+            vals = np.concatenate([vals[: at + k - 1], vals[at + k:]])
+        elif variant == "one_empty":
+            lens = lens.copy()
+            at = int(lens[: n - 1].sum())
+            lens[n - 1] = 0
+            vals = vals[:at]
+        data = (lens, vals)
+        ref = O.filter_perfdata(op, t, ranks, data)
+        cols = _perf_cols(codec, t, ranks, data, n)
+        if variant == "offset":
+            # the packets' arrays behind five elements nobody owns
+            pad = torch.zeros(5, dtype=cols[2].values.dtype, device=codec.device)
+            cols[2].values = torch.cat([pad, cols[2].values])
+            cols[2].offs = cols[2].offs + 5
+            cols[2].capacity = cols[2].values.numel()
+        got = _perf_result(t, *codec.filter_perfdata(op, t, cols[0], cols[2], n, group=0, out_cap=k))
+        assert got[0] == ref[0] and got[1].size == ref[1].size, (variant, got, ref)
+        assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (variant, got[1][:4], ref[1][:4])
+    assert codec.status() == 0
