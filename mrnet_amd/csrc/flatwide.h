@@ -713,7 +713,14 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
 // device: shape[0] = 1 if the wave has that form (0 switches the launch off), shape[1] = k, shape[2] =
 // first (the element index of packet 0's array in the values column).  Column y has its summaries at
 // ws_base + y * ws_stride and its result at result + 16 y.
-struct WideMulti { const uint64_t *shape; uint64_t ws_stride; };
+// fronts / nodes (both or neither): column y continues from the node fronts[y] and leaves the node nodes[y]
+// instead of a result (a packet range of a wave, FilterLink).
+struct WideMulti { const uint64_t *shape; uint64_t ws_stride; const Partial *fronts; Partial *nodes; };
+
+__device__ __forceinline__ FilterLink wide_multi_link(const WideMulti &m)
+{
+    return FilterLink{ m.fronts ? m.fronts + blockIdx.y : nullptr, m.nodes ? m.nodes + blockIdx.y : nullptr };
+}
 
 template <typename T> __device__ __forceinline__ bool wide_multi_column(const WideMulti &m, FilterIn &in)
 {
@@ -735,12 +742,12 @@ template <int OP, typename T>
 __global__ __launch_bounds__(WIDE_TPB) void k_wide_maps_multi(FilterIn in, void *ws_base, uint64_t nc, WideMulti m)
 {
     if (!wide_multi_column<T>(m, in)) return;
-    wide_maps_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, FilterLink{ nullptr, nullptr });
+    wide_maps_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, wide_multi_link(m));
 }
 
 template <int OP, typename T>
 __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk_multi(FilterIn in, void *ws_base, uint64_t nc, uint8_t *result, int32_t *result_ok, WideMulti m)
 {
     if (!wide_multi_column<T>(m, in)) return;
-    wide_walk_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, result + 16u * blockIdx.y, result_ok + blockIdx.y, FilterLink{ nullptr, nullptr });
+    wide_walk_body<OP, T>(in, (uint8_t *)ws_base + blockIdx.y * m.ws_stride, nc, result + 16u * blockIdx.y, result_ok + blockIdx.y, wide_multi_link(m));
 }

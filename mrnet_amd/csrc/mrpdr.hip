@@ -1757,7 +1757,8 @@ static uint64_t perf_columns_ws_stride(uint64_t n)
 }
 static uint64_t perf_columns_bytes(uint64_t n, uint64_t out_cap)
 {
-    return 64 + up16(4 * n) + up16(16 * out_cap) + up16(4 * out_cap) + out_cap * perf_columns_ws_stride(n);
+    // shape words | weights | results (or: front nodes, nodes) | result flags | summaries
+    return 64 + up16(4 * n) + 2 * up16(16 * out_cap) + up16(4 * out_cap) + out_cap * perf_columns_ws_stride(n);
 }
 
 extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
@@ -1976,17 +1977,17 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
             uint64_t *shape = (uint64_t *)p;                    // [0] regular, [1] k, [2] first, [3] total ranks
             uint32_t *irregular = (uint32_t *)(p + 32);         p += 64;
             int32_t *nranks = (int32_t *)p;                     p += up16(4 * n);
-            uint8_t *results = p;                               p += up16(16 * out_cap);
+            uint8_t *results = p;                               p += 2 * up16(16 * out_cap);
             int32_t *oks = (int32_t *)p;                        p += up16(4 * out_cap);
             void *ws = p;
             const uint64_t nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
             HIP_OK(hipMemsetAsync(scratch, 0, 64, st));
             k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, out_cap, shape, nranks, irregular);
             LAUNCHED("k_perf_shape");
-            k_perf_shape_verdict<<<1, 1, 0, st>>>(shape, irregular);
+            k_perf_shape_verdict<<<1, 64, 0, st>>>(shape, irregular, nullptr, nullptr);
             LAUNCHED("k_perf_shape_verdict");
             FilterIn fin = { (const uint8_t *)data->values, 0, (const uint8_t *)nranks, 4, n, 0, nullptr };
-            const WideMulti m = { shape, perf_columns_ws_stride(n) };
+            const WideMulti m = { shape, perf_columns_ws_stride(n), nullptr, nullptr };
             const dim3 wide((uint32_t)nc, (uint32_t)out_cap), one(1, (uint32_t)out_cap);
             if (op == MRPDR_SUM) {
                 k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
@@ -2041,6 +2042,42 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
     PerfRaw raw = { nullptr, &h->last, (const uint8_t *)front, &h->packets, nullptr };
     const uint64_t all[1] = { 0 };
     PerfPlan plan = perf_plan(n, all, 1);
+    if (chained && (op == MRPDR_SUM || op == MRPDR_AVG) && n >= PERF_COLUMNS_MIN && cap && cap <= PERF_COLUMNS_MAX_CAP && scratch &&
+        !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, cap)) {
+        // doubles whose arrays all have one length (and a state in front of the same form): the elements'
+        // chains as strided columns, each continued from the front's accumulator (see mrpdr_wave_perfdata);
+        // the serial fold below runs only if the device finds the wave, or the front, to be of another form
+        uint8_t *p = (uint8_t *)scratch;
+        uint64_t *shape = (uint64_t *)p;
+        uint32_t *irregular = (uint32_t *)(p + 32);         p += 64;
+        int32_t *nranks = (int32_t *)p;                     p += up16(4 * n);
+        Partial *fronts = (Partial *)p;                     p += up16(16 * cap);
+        Partial *nodes = (Partial *)p;                      p += up16(16 * cap);
+        p += up16(4 * cap);
+        void *ws = p;
+        const uint64_t nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
+        HIP_OK(hipMemsetAsync(scratch, 0, 64, st));
+        k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, cap, shape, nranks, irregular);
+        LAUNCHED("k_perf_shape");
+        k_perf_shape_verdict<<<1, 64, 0, st>>>(shape, irregular, (const uint8_t *)front, fronts);
+        LAUNCHED("k_perf_shape_verdict");
+        FilterIn fin = { (const uint8_t *)data->values, 0, (const uint8_t *)nranks, 4, n, 0, nullptr };
+        const WideMulti m = { shape, perf_columns_ws_stride(n), front ? fronts : nullptr, nodes };
+        const dim3 wide((uint32_t)nc, (uint32_t)cap), one(1, (uint32_t)cap);
+        if (op == MRPDR_SUM) {
+            k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+            k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+            k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
+        } else {
+            k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+            k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
+            k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
+        }
+        LAUNCHED("k_wide_*_multi");
+        k_perf_state_from_columns<<<1, 64, 0, st>>>(shape, nodes, (const uint8_t *)front, sp);
+        LAUNCHED("k_perf_state_from_columns");
+        raw.unless = shape;
+    }
     if (!chained && n >= PERF_FREE_MIN && perf_lanes(cap) <= 64) {
         const PerfPlan free_plan = perf_plan(n, PERF_FREE_FANINS, PERF_FREE_LEVELS);
         if (scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_plan_bytes(free_plan, cap)) plan = free_plan;

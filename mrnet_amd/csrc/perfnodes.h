@@ -315,9 +315,43 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_shape(PerfIn in, uint64_t ca
 }
 
 // (a launch of its own: every workgroup of k_perf_shape has to have spoken)
-__global__ void k_perf_shape_verdict(uint64_t *shape, const uint32_t *irregular)
+// front (a state handed over by whoever folded the packets in front, or NULL): the columns go on from it
+// only if it has the same form -- every element covered by every packet so far, k of them; its
+// accumulators then become the columns' front nodes.
+__global__ void k_perf_shape_verdict(uint64_t *shape, const uint32_t *irregular, const uint8_t *front, Partial *fronts)
 {
-    shape[0] = *irregular ? 0u : 1u;
+    bool regular = *irregular == 0;
+    const uint64_t k = shape[1];
+    if (front) {
+        const PerfState h = *reinterpret_cast<const PerfState *>(front);
+        if (h.packets && (h.longest != k || h.last != k)) regular = false;
+        if (regular && threadIdx.x < k) {
+            Partial p;
+            p.bits = h.packets ? reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x] : 0;
+            p.cnt = h.packets ? 0 - h.rank : 0;
+            p.present = h.packets ? 1 : 0;
+            fronts[threadIdx.x] = p;
+        }
+    }
+    if (threadIdx.x == 0) shape[0] = regular ? 1u : 0u;
+}
+
+// the columns' nodes behind a packet range into the range's state (struct mrpdr_perf_state + accumulators)
+__global__ void k_perf_state_from_columns(const uint64_t *shape, const Partial *nodes, const uint8_t *front, uint8_t *state)
+{
+    if (!shape[0]) return;
+    const uint64_t k = shape[1];
+    if (threadIdx.x < k) reinterpret_cast<uint64_t *>(state + sizeof(PerfState))[threadIdx.x] = nodes[threadIdx.x].bits;
+    if (threadIdx.x == 0) {
+        uint32_t total = (uint32_t)shape[3];
+        if (front) {
+            const PerfState h = *reinterpret_cast<const PerfState *>(front);
+            if (h.packets) total += (uint32_t)(0 - h.rank);
+        }
+        PerfState out;
+        out.longest = k; out.last = k; out.rank = 0 - (int32_t)total; out.packets = 1; out.reserved = 0;
+        *reinterpret_cast<PerfState *>(state) = out;
+    }
 }
 
 // the k results of the strided fold into the output packet

@@ -446,3 +446,39 @@ def test_perfdata_double_one_invocation_regular_waves(codec, op, n, k):
         assert got[0] == ref[0] and got[1].size == ref[1].size, (variant, got, ref)
         assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (variant, got[1][:4], ref[1][:4])
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG])
+def test_perfdata_double_ranges_relay_the_columns(codec, op):
+    """A regular double wave in ranges large enough for the strided exact fold: every range continues
+    the elements' chains from the state in front (fronts of the same form go on as columns; a range of
+    another form -- ragged lengths -- and whatever follows it take the serial fold from that state on).
+    Against ONE oracle invocation over the whole wave."""
+    t, k = O.DOUBLE_T, 8
+    for n, edges, ragged_range in ((60000, [0, 20000, 40000, 60000], None), (50000, [0, 9000, 30000, 30000, 50000], None),
+                                   (45000, [0, 15000, 30000, 45000], 1), (30000, [0, 10000, 20000, 30000], 0)):
+        ranks, data = perf_wave(n, t, seed=n + op, kmax=k, same_len=True, aggregated=True)
+        lens, vals = data
+        if ragged_range is not None:
+            lo = edges[ragged_range]
+            lens = lens.copy()
+            at = int(lens[: lo + 7].sum())
+            lens[lo + 7] = k - 3                              # one shorter array inside that range
+            vals = np.concatenate([vals[: at + k - 3], vals[at + k:]])
+        data = (lens, vals)
+        ref = O.filter_perfdata(op, t, ranks, data)
+        ro = np.zeros(n + 1, np.int64); np.cumsum(ranks[0], out=ro[1:])
+        do = np.zeros(n + 1, np.int64); np.cumsum(data[0], out=do[1:])
+        front, states = None, []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi > lo:
+                cols = _perf_cols(codec, t, (ranks[0][lo:hi], ranks[1][ro[lo]:ro[hi]]), (data[0][lo:hi], data[1][do[lo]:do[hi]]), hi - lo)
+                front = codec.perfdata_partial(op, t, cols[0], cols[2], hi - lo, k, front)
+            else:
+                empty = W.Column(None, None, None, 0)
+                front = codec.perfdata_partial(op, t, empty, empty, 0, k, front)
+            states.append(front)
+        got = _perf_result(t, *codec.perfdata_combine(op, t, torch.stack(states), k))
+        assert got[0] == ref[0] and got[1].size == ref[1].size, (n, got, ref)
+        assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, ragged_range, got[1][:4], ref[1][:4])
+    assert codec.status() == 0
