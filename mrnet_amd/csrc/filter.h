@@ -200,7 +200,7 @@ __device__ inline void write_result(uint8_t *result, int32_t *result_ok, bool pr
     st_u<uint64_t>(result, lo);
     st_u<uint64_t>(result + 8, hi);
     if (result_ok) {
-        __threadfence_system();
+        __threadfence_system();             // (measured: 0.15-0.25 us of a 4.6 us call; the release store alone 0.2 more than a plain one)
         __hip_atomic_store(result_ok, present ? 1 : 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

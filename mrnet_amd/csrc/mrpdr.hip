@@ -1971,7 +1971,7 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
         // Doubles, SUM / AVG: if every packet carries the same number of elements, end to end, the elements
         // are strided columns and their chains of roundings are taken by the device-wide exact fold, side
         // by side; the device finds out (k_perf_shape), and the serial fold below runs only if not.
-        if (type == MRPDR_DOUBLE_T && (op == MRPDR_SUM || op == MRPDR_AVG) && n >= PERF_COLUMNS_MIN && out_cap &&
+        if (type == MRPDR_DOUBLE_T && n >= PERF_COLUMNS_MIN && out_cap &&
             out_cap <= PERF_COLUMNS_MAX_CAP && scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, out_cap)) {
             uint8_t *p = (uint8_t *)scratch;
             uint64_t *shape = (uint64_t *)p;                    // [0] regular, [1] k, [2] first, [3] total ranks
@@ -1995,12 +1995,29 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
                 k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
                 LAUNCHED("k_wide_*_multi");
                 k_perf_from_columns<MRPDR_SUM><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
-            } else {
+            } else if (op == MRPDR_AVG) {
                 k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
                 k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
                 k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
                 LAUNCHED("k_wide_*_multi");
                 k_perf_from_columns<MRPDR_AVG><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
+            } else {
+                // MIN / MAX: the elements' trees side by side (the summaries' room holds their nodes)
+                const uint32_t tiles = blocks_for(n, FILTER_TILE);
+                Partial *fronts = (Partial *)(results + up16(16 * out_cap));
+                WideMulti mm = m;
+                const dim3 tg(tiles, (uint32_t)out_cap);
+                if (op == MRPDR_MIN) {
+                    k_tree_tile_multi<OP_MINR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
+                    k_tree_top_multi<OP_MINR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, results, oks, mm);
+                    k_perf_from_columns<MRPDR_MIN><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
+                } else {
+                    k_perf_minmax_fronts<MRPDR_MAX><<<1, 64, 0, st>>>(shape, nullptr, fronts);
+                    mm.fronts = fronts;
+                    k_tree_tile_multi<OP_MAXR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
+                    k_tree_top_multi<OP_MAXR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, results, oks, mm);
+                    k_perf_from_columns<MRPDR_MAX><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
+                }
             }
             LAUNCHED("k_perf_from_columns");
             PerfRaw unless_regular = none;
@@ -2042,7 +2059,7 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
     PerfRaw raw = { nullptr, &h->last, (const uint8_t *)front, &h->packets, nullptr };
     const uint64_t all[1] = { 0 };
     PerfPlan plan = perf_plan(n, all, 1);
-    if (chained && (op == MRPDR_SUM || op == MRPDR_AVG) && n >= PERF_COLUMNS_MIN && cap && cap <= PERF_COLUMNS_MAX_CAP && scratch &&
+    if (chained && n >= PERF_COLUMNS_MIN && cap && cap <= PERF_COLUMNS_MAX_CAP && scratch &&
         !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, cap)) {
         // doubles whose arrays all have one length (and a state in front of the same form): the elements'
         // chains as strided columns, each continued from the front's accumulator (see mrpdr_wave_perfdata);
@@ -2068,10 +2085,24 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
             k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
             k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
             k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
-        } else {
+        } else if (op == MRPDR_AVG) {
             k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
             k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
             k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
+        } else {
+            const uint32_t tiles = blocks_for(n, FILTER_TILE);
+            WideMulti mm = m;
+            mm.fronts = fronts;                 // (the state in front, or MAX's start value; MIN without a front: absent nodes)
+            const dim3 tg(tiles, (uint32_t)cap);
+            if (op == MRPDR_MIN) {
+                k_perf_minmax_fronts<MRPDR_MIN><<<1, 64, 0, st>>>(shape, (const uint8_t *)front, fronts);
+                k_tree_tile_multi<OP_MINR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
+                k_tree_top_multi<OP_MINR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, nullptr, nullptr, mm);
+            } else {
+                k_perf_minmax_fronts<MRPDR_MAX><<<1, 64, 0, st>>>(shape, (const uint8_t *)front, fronts);
+                k_tree_tile_multi<OP_MAXR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
+                k_tree_top_multi<OP_MAXR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, nullptr, nullptr, mm);
+            }
         }
         LAUNCHED("k_wide_*_multi");
         k_perf_state_from_columns<<<1, 64, 0, st>>>(shape, nodes, (const uint8_t *)front, sp);
@@ -2096,7 +2127,8 @@ extern "C" int32_t mrpdr_wave_perfdata_combine(mrpdr_ctx *c, int32_t op, int32_t
     if (out_cap && !out_data) return fail("%s: NULL out_data", who);
     const uint64_t stride = mrpdr_perfdata_state_bytes(cap);
     const uint8_t *sp = (const uint8_t *)states;
-    if (mrpdr_perfdata_is_chained(op, type)) { sp += (g - 1) * stride; g = 1; }     // relayed: the last state holds the whole fold
+    const int32_t relayed = mrpdr_perfdata_is_chained(op, type);
+    if (relayed) { sp += (g - 1) * stride; g = 1; }     // the last state holds the whole fold
     PerfOut o = { out_data, out_cap, out_len, nullptr, out_rank, nullptr, nullptr, c->status };
     const uint64_t span = cap > out_cap ? cap : out_cap;
     const uint32_t xb = blocks_for(span ? span : 1, MRPDR_TPB);
@@ -2104,7 +2136,7 @@ extern "C" int32_t mrpdr_wave_perfdata_combine(mrpdr_ctx *c, int32_t op, int32_t
     return perf_type(who, type, [&](auto tv) {
         typedef decltype(tv) T;
         return perf_op<T>(who, op, [&](auto opv) {
-            k_perf_combine<decltype(opv)::value, T><<<xb, MRPDR_TPB, 0, st>>>(sp, g, stride, o);
+            k_perf_combine<decltype(opv)::value, T><<<xb, MRPDR_TPB, 0, st>>>(sp, g, stride, o, relayed);
             LAUNCHED("k_perf_combine");
             return 1;
         });

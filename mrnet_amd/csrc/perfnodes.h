@@ -253,7 +253,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_nodes(PerfLevel a)
 // data arrives relayed -- every range continued the fold from the state in front of it -- so the caller
 // passes the last state alone and this is its division and its way into the packet's form.
 template <int OP, typename T>
-__global__ __launch_bounds__(MRPDR_TPB) void k_perf_combine(const uint8_t *states, uint64_t g, uint64_t stride, PerfOut out)
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_combine(const uint8_t *states, uint64_t g, uint64_t stride, PerfOut out, int32_t relayed)
 {
     const uint64_t u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     T acc;
@@ -266,7 +266,11 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_combine(const uint8_t *state
         total += (uint32_t)(0 - h.rank);
         longest = h.longest > longest ? h.longest : longest;
         last = h.last;
-        if (u < h.longest) acc = perf_fold<OP, T>(acc, reinterpret_cast<const T *>(states + s * stride + sizeof(PerfState))[u], 1);
+        if (u < h.longest) {
+            const T x = reinterpret_cast<const T *>(states + s * stride + sizeof(PerfState))[u];
+            // (a relayed state IS the accumulator, start value and all: a MAX that a NaN restarted may lie below 0)
+            acc = relayed ? x : perf_fold<OP, T>(acc, x, 1);
+        }
     }
     if (OP == MRPDR_AVG && last && u < last) acc = acc / (T)total;
     if (longest > out.stride) {
@@ -366,4 +370,46 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_from_columns(const uint64_t 
     }
     if (u < k) reinterpret_cast<uint64_t *>(out.data)[u] = *reinterpret_cast<const uint64_t *>(results + 16 * u);
     if (u == 0) { out.lens[0] = k; out.ranks[0] = 0 - (int32_t)(uint32_t)shape[3]; }
+}
+
+// MIN / MAX of the same regular double waves: the comparison keeps the later operand whenever it is false,
+// so a NaN restarts the fold -- the (value, restarted) nodes of OP_MINR / OP_MAXR carry that through a
+// tree, and the elements' trees run side by side (blockIdx.y = element).  tfilter_PerfData's MAX starts
+// from 0 rather than from the first packet (src/FilterDefinitions.C:961-965): that 0 is the front node.
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_tree_tile_multi(FilterIn in, Partial *partials, uint64_t pstride, WideMulti m)
+{
+    __shared__ Partial wave_part[MRPDR_TPB / 64];
+    if (!wide_multi_column<T>(m, in)) return;
+    T vals[FILTER_LEAF];
+    int32_t cnts[FILTER_LEAF];
+    const int nvalid = tile_load<T, false>(in, vals, cnts);
+#pragma unroll
+    for (int k = 0; k < FILTER_LEAF; k++) cnts[k] = vals[k] != vals[k];
+    const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
+    if (threadIdx.x == 0) partials[blockIdx.y * pstride + blockIdx.x] = out;
+}
+
+template <int OP, typename T>
+__global__ __launch_bounds__(MRPDR_TPB) void k_tree_top_multi(const Partial *partials, uint64_t np, uint64_t pstride, uint8_t *results,
+                                                              int32_t *oks, WideMulti m)
+{
+    __shared__ Partial stage[FLAT_TILE];
+    if (!m.shape[0] || blockIdx.y >= m.shape[1]) return;
+    tree_top<OP, T>(partials + blockIdx.y * pstride, np, results + 16u * blockIdx.y, oks + blockIdx.y, stage, wide_multi_link(m));
+}
+
+// the front nodes of MIN / MAX columns: the state in front if there is one, else MAX's start value 0
+// (MIN's start, a NaN, is the same as no front at all: the first comparison discards it)
+template <int OP>
+__global__ void k_perf_minmax_fronts(const uint64_t *shape, const uint8_t *front, Partial *fronts)
+{
+    if (!shape[0] || threadIdx.x >= shape[1]) return;
+    Partial p;
+    p.bits = 0; p.cnt = 0; p.present = OP == MRPDR_MAX ? 1 : 0;
+    if (front) {
+        const PerfState h = *reinterpret_cast<const PerfState *>(front);
+        if (h.packets) { p.bits = reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x]; p.present = 1; }
+    }
+    fronts[threadIdx.x] = p;
 }

@@ -410,7 +410,7 @@ def test_perfdata_in_ranges_equals_one_invocation(codec, t, op):
     assert codec.status() == 0
 
 
-@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN, W.TFILTER_MAX])
 @pytest.mark.parametrize("n,k", [(8192, 8), (20001, 3), (131072, 8), (40000, 64), (9000, 1)])
 def test_perfdata_double_one_invocation_regular_waves(codec, op, n, k):
     """One invocation over doubles is a chain of roundings per element.  When every packet carries the
@@ -420,9 +420,14 @@ def test_perfdata_double_one_invocation_regular_waves(codec, op, n, k):
     made shorter or empty (the device finds out and the serial fold runs), and with a first array that
     does not start the values column."""
     t = O.DOUBLE_T
-    for variant in ("regular", "one_short", "one_empty", "offset"):
+    for variant in ("regular", "one_short", "one_empty", "offset", "negative"):
         ranks, data = perf_wave(n, t, seed=n + k + op, kmax=k, same_len=True, aggregated=True)
         lens, vals = data
+        if op in (W.TFILTER_MIN, W.TFILTER_MAX):
+            vals = vals.copy()
+            vals[:: max(1, vals.size // 40)] = np.nan          # NaNs restart the comparison
+            if variant == "negative":
+                vals = -np.abs(vals)                           # MAX starts from 0: all-negative data gives 0 (or a late NaN)
         if variant == "one_short" and k > 1:
             lens = lens.copy()
             at = int(lens[: n // 2].sum())
@@ -448,7 +453,7 @@ def test_perfdata_double_one_invocation_regular_waves(codec, op, n, k):
     assert codec.status() == 0
 
 
-@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG])
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN, W.TFILTER_MAX])
 def test_perfdata_double_ranges_relay_the_columns(codec, op):
     """A regular double wave in ranges large enough for the strided exact fold: every range continues
     the elements' chains from the state in front (fronts of the same form go on as columns; a range of
@@ -459,6 +464,10 @@ def test_perfdata_double_ranges_relay_the_columns(codec, op):
                                    (45000, [0, 15000, 30000, 45000], 1), (30000, [0, 10000, 20000, 30000], 0)):
         ranks, data = perf_wave(n, t, seed=n + op, kmax=k, same_len=True, aggregated=True)
         lens, vals = data
+        if op in (W.TFILTER_MIN, W.TFILTER_MAX):
+            vals = -np.abs(vals)
+            vals[:: 997] = np.nan
+            vals[edges[1] * k - 3: edges[1] * k + 2] = np.nan     # NaNs on both sides of a range boundary
         if ragged_range is not None:
             lo = edges[ragged_range]
             lens = lens.copy()
