@@ -78,6 +78,17 @@ def test_format_compiler_rejects(fmt):
     assert capi.last_error()
 
 
+def test_format_token_bound_is_exact():
+    """32 tokens compile, 33 are refused with a message (the reference's tokenizer has no bound,
+    src/Packet.C:608-619; the field table of this library is a kernel argument of fixed size)."""
+    lib = capi.load()
+    h = lib.mrpdr_fmt_compile(" ".join(["%d"] * 32).encode())
+    assert h and lib.mrpdr_fmt_nfields(h) == 32
+    lib.mrpdr_fmt_free(h)
+    assert not lib.mrpdr_fmt_compile(" ".join(["%d"] * 33).encode())
+    assert "32" in capi.last_error()
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():
