@@ -19,6 +19,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -48,6 +49,9 @@ def parse():
     p.add_argument("--backend", default="nccl", help="nccl (= RCCL) for the real run; gloo to rehearse "
                                                      "several ranks on one GPU")
     p.add_argument("--one-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    p.add_argument("--exchange-timeout", type=int, default=240,
+                   help="N > 1: seconds the sharded-filter leg behind the timed region may take before every "
+                        "rank gives up on it (the headline line is printed either way)")
     p.add_argument("--perf-every", type=int, default=5,
                    help="bracket the payload kernels of every k-th step with HIP events (1 = every step)")
     p.add_argument("--overlap", action="store_true",
@@ -1083,7 +1087,24 @@ def main():
             out["cpu_baseline"]["host_to_host_us"] = h2h
     if world > 1:
         # (a failure here -- the same on every rank, the inputs are seeded -- must not cost the
-        # headline line that is already measured: it is reported in the line instead)
+        # headline line that is already measured: it is reported in the line instead; and a rank that
+        # waits in a collective for one that failed alone must not cost it either: after
+        # --exchange-timeout seconds every rank gives up, rank 0 prints the line as it stands)
+        printed = threading.Lock()
+
+        def give_up():
+            if not printed.acquire(blocking=False):
+                return
+            print("rank %d: the sharded filter leg did not finish within %d s" % (rank, a.exchange_timeout), file=sys.stderr)
+            if rank == 0:
+                out.pop("extra", None)
+                out["extra_error"] = "the sharded filter leg did not finish within %d s" % a.exchange_timeout
+                out.setdefault("cpu_baseline", None)
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(a.exchange_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             # the one exchange step of the path: a '%lf %d' wave of world x 131,072
             # packets, fused Avg per shard, results all-gathered (RCCL) and folded in rank order
@@ -1147,12 +1168,20 @@ def main():
             print("rank %d: sharded filter leg failed: %r" % (rank, e), file=sys.stderr)
             if rank == 0:
                 out["extra_error"] = repr(e)
+        watchdog.cancel()
+        if not printed.acquire(blocking=False):         # the watchdog is printing: it ends the process
+            time.sleep(60)
     if rank == 0:
         out.setdefault("cpu_baseline", None)
         print(json.dumps(out), flush=True)
     if world > 1:
+        # (the line is out: a rank that is gone must not keep the others in the last barrier)
+        bye = threading.Timer(60, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":

@@ -17,7 +17,9 @@
 
 struct Bar { unsigned int leaf[64 * 32]; unsigned int root; unsigned int gen; unsigned int err; unsigned int pad[29]; unsigned int gens[64 * 32]; };   // (leaf / gens: one 128-byte line per group)
 
-template <int GROUP, bool SPREAD>
+// RELAXED: the polls are relaxed loads (no cache invalidation per poll), one acquire fence when the
+// generation has moved.
+template <int GROUP, bool SPREAD, bool RELAXED = false>
 __device__ inline bool grid_barrier(Bar *b, unsigned int nblocks, unsigned int target_gen)
 {
     __syncthreads();
@@ -37,9 +39,17 @@ __device__ inline bool grid_barrier(Bar *b, unsigned int nblocks, unsigned int t
         }
         unsigned int spins = 0;
         const unsigned int *word = SPREAD ? &b->gens[g * 32] : &b->gen;
-        while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target_gen) {
-            if (++spins > SPIN_LIMIT) { b->err = 1; fine = false; break; }
-            __builtin_amdgcn_s_sleep(1);
+        if (RELAXED) {
+            while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target_gen) {
+                if (++spins > SPIN_LIMIT) { b->err = 1; fine = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        } else {
+            while (__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target_gen) {
+                if (++spins > SPIN_LIMIT) { b->err = 1; fine = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
     }
     __syncthreads();
@@ -47,13 +57,13 @@ __device__ inline bool grid_barrier(Bar *b, unsigned int nblocks, unsigned int t
 }
 
 // `rounds` barriers in a row, a little work in between (one load and one store per thread)
-template <int GROUP, bool SPREAD>
+template <int GROUP, bool SPREAD, bool RELAXED>
 __global__ __launch_bounds__(256) void k_barriers(Bar *b, unsigned int nblocks, unsigned int base_gen, int rounds, const uint32_t *in, uint32_t *out)
 {
     __shared__ uint8_t image[24576];
     image[threadIdx.x] = (uint8_t)in[blockIdx.x * 256 + threadIdx.x];
     for (int r = 0; r < rounds; r++) {
-        if (!grid_barrier<GROUP, SPREAD>(b, nblocks, base_gen + (unsigned int)r + 1)) break;
+        if (!grid_barrier<GROUP, SPREAD, RELAXED>(b, nblocks, base_gen + (unsigned int)r + 1)) break;
         out[blockIdx.x * 256 + threadIdx.x] = image[(threadIdx.x + r) & 255] + (uint32_t)r;
     }
 }
@@ -77,7 +87,7 @@ template <typename F> static float timeit(F f, int reps)
     return ms / reps;
 }
 
-template <int GROUP, bool SPREAD> static void run(Bar *bar, unsigned int nblocks, const uint32_t *in, uint32_t *out)
+template <int GROUP, bool SPREAD, bool RELAXED = false> static void run(Bar *bar, unsigned int nblocks, const uint32_t *in, uint32_t *out)
 {
     unsigned int gen = 0;
     CK(hipMemset(bar, 0, sizeof(Bar)));
@@ -85,11 +95,11 @@ template <int GROUP, bool SPREAD> static void run(Bar *bar, unsigned int nblocks
     const int rounds[3] = { 0, 2, 10 };
     for (int k = 0; k < 3; k++) {
         const int r = rounds[k];
-        t[k] = timeit([&] { k_barriers<GROUP, SPREAD><<<nblocks, 256>>>(bar, nblocks, gen, r, in, out); gen += (unsigned int)r; }, 50);
+        t[k] = timeit([&] { k_barriers<GROUP, SPREAD, RELAXED><<<nblocks, 256>>>(bar, nblocks, gen, r, in, out); gen += (unsigned int)r; }, 50);
     }
     Bar h;
     CK(hipMemcpy(&h, bar, sizeof h, hipMemcpyDeviceToHost));
-    printf("groups of %4d%s: launch alone %.2f us, with 2 barriers %.2f us, with 10 barriers %.2f us -> %.2f us per barrier%s\n", GROUP, SPREAD ? ", a poll word per group" : "",
+    printf("groups of %4d%s: launch alone %.2f us, with 2 barriers %.2f us, with 10 barriers %.2f us -> %.2f us per barrier%s\n", GROUP, SPREAD ? (RELAXED ? ", a poll word per group, relaxed polls" : ", a poll word per group") : (RELAXED ? ", relaxed polls" : ""),
            t[0] * 1e3, t[1] * 1e3, t[2] * 1e3, (t[2] - t[0]) * 1e3 / 10, h.err ? "  (A SPIN RAN OUT: barrier failed)" : "");
 }
 
@@ -99,7 +109,7 @@ int main()
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     int per_cu = 0;
-    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_barriers<32, false>, 256, 0));
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_barriers<32, false, false>, 256, 0));
     printf("%d CUs, %d workgroups of the barrier kernel fit a CU: %d resident at once (%u needed)\n", prop.multiProcessorCount, per_cu,
            per_cu * prop.multiProcessorCount, nblocks);
     if ((unsigned int)(per_cu * prop.multiProcessorCount) < nblocks) { printf("not all workgroups would be resident: not run\n"); return 1; }
@@ -111,6 +121,9 @@ int main()
     run<128, true>(bar, nblocks, in, out);
     run<32, true>(bar, nblocks, in, out);
     run<16, true>(bar, nblocks, in, out);
+    run<1024, false, true>(bar, nblocks, in, out);
+    run<32, false, true>(bar, nblocks, in, out);
+    run<128, true, true>(bar, nblocks, in, out);
     const float tp = timeit([&] { k_plain<<<nblocks, 256>>>(in, out, 1); k_plain<<<nblocks, 256>>>(in, out, 2); k_plain<<<nblocks, 256>>>(in, out, 3); }, 50);
     const float t1 = timeit([&] { k_plain<<<nblocks, 256>>>(in, out, 1); }, 50);
     printf("three dependent launches of the same work: %.2f us, one: %.2f us -> %.2f us per kernel boundary\n", tp * 1e3, t1 * 1e3, (tp - t1) * 1e3 / 2);
