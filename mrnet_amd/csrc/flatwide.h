@@ -710,12 +710,14 @@ __global__ __launch_bounds__(WIDE_TPB) void k_wide_walk(FilterIn in, void *ws_ba
 // performance-data packets whose arrays all have one length k and lie end to end: element y of every
 // packet is a column (values at base + (first + y) * sizeof(T), k * sizeof(T) apart), and the elements'
 // chains run next to each other, one walking workgroup each.  What the host does not know is read on the
-// device: shape[0] = 1 if the wave has that form (0 switches the launch off), shape[1] = k, shape[2] =
-// first (the element index of packet 0's array in the values column).  Column y has its summaries at
+// device: shape[0] != 0 if the wave has that form (0 switches the launch off), shape[1] = columns, shape[2] =
+// first (the element index of packet 0's array in the values column), shape[6] = elements from packet to packet.  Column y has its summaries at
 // ws_base + y * ws_stride and its result at result + 16 y.
 // fronts / nodes (both or neither): column y continues from the node fronts[y] and leaves the node nodes[y]
 // instead of a result (a packet range of a wave, FilterLink).
-struct WideMulti { const uint64_t *shape; uint64_t ws_stride; const Partial *fronts; Partial *nodes; };
+// dense / row_counts: the dense copy of a wave whose arrays are not of one length (shape[7] = 1 puts the
+// columns there, shape[6] elements from packet to packet) and the packets' own array lengths.
+struct WideMulti { const uint64_t *shape; uint64_t ws_stride; const Partial *fronts; Partial *nodes; const uint8_t *dense; const uint64_t *row_counts; };
 
 __device__ __forceinline__ FilterLink wide_multi_link(const WideMulti &m)
 {
@@ -724,10 +726,11 @@ __device__ __forceinline__ FilterLink wide_multi_link(const WideMulti &m)
 
 template <typename T> __device__ __forceinline__ bool wide_multi_column(const WideMulti &m, FilterIn &in)
 {
-    const uint64_t on = m.shape[0], k = m.shape[1], first = m.shape[2];
-    if (!on || blockIdx.y >= k) return false;
+    const uint64_t on = m.shape[0], cols = m.shape[1], first = m.shape[2];
+    if (!on || blockIdx.y >= cols) return false;
+    if (m.shape[7]) in.values = m.dense;
     in.values += (first + blockIdx.y) * sizeof(T);
-    in.value_stride = k * sizeof(T);
+    in.value_stride = m.shape[6] * sizeof(T);
     return true;
 }
 

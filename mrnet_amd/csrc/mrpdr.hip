@@ -1747,18 +1747,73 @@ extern "C" uint64_t mrpdr_perfdata_levels_scratch_bytes(uint64_t n, const uint64
     return perf_plan_bytes(perf_plan(n, fanins, nlevels), out_cap);
 }
 
-// One invocation over doubles whose arrays all have one length: the elements as strided columns through the
-// device-wide exact fold (perfnodes.h, k_perf_shape).  Room: shape words, the weights, results, summaries.
+// One invocation over doubles: the elements as strided columns through the device-wide exact fold, in place
+// when the arrays all have one length, from a dense copy otherwise (perfnodes.h, k_perf_shape).
 #define PERF_COLUMNS_MIN FLAT_WIDE_MIN_DOUBLE       // packets from which the strided fold is tried
 #define PERF_COLUMNS_MAX_CAP 64u                    // elements per packet at most (one walking workgroup each)
 static uint64_t perf_columns_ws_stride(uint64_t n)
 {
     return up16(WideWs<double>::bytes((n + WIDE_CHUNK - 1) / WIDE_CHUNK));
 }
-static uint64_t perf_columns_bytes(uint64_t n, uint64_t out_cap)
+struct PerfColumns {            // the scratch of that path, carved up
+    uint64_t *shape; int32_t *nranks; Partial *fronts, *nodes; void *ws; uint64_t *dense; uint64_t bytes;
+};
+static PerfColumns perf_columns(void *scratch, uint64_t n, uint64_t cap)
 {
-    // shape words | weights | results (or: front nodes, nodes) | result flags | summaries
-    return 64 + up16(4 * n) + 2 * up16(16 * out_cap) + up16(4 * out_cap) + out_cap * perf_columns_ws_stride(n);
+    uint8_t *p = (uint8_t *)scratch;
+    PerfColumns c;
+    c.shape = (uint64_t *)p;    p += PERF_SHAPE_WORDS * 8;
+    c.nranks = (int32_t *)p;    p += up16(4 * n);
+    c.fronts = (Partial *)p;    p += up16(16 * cap);
+    c.nodes = (Partial *)p;     p += up16(16 * cap);
+    c.ws = p;                   p += cap * perf_columns_ws_stride(n);
+    c.dense = (uint64_t *)p;    p += up16(8 * n * cap);
+    c.bytes = (uint64_t)(p - (uint8_t *)scratch);
+    return c;
+}
+static uint64_t perf_columns_bytes(uint64_t n, uint64_t out_cap) { return perf_columns(nullptr, n, out_cap).bytes; }
+
+// The column passes of one PerfData operator over the packets `in` (doubles): shape and weights, the dense
+// copy if the device finds the wave ragged, then the elements' chains (SUM / AVG) or trees (MIN / MAX) side
+// by side, each from its front node (a state handed over, or the operator's start value) to its node.
+static int32_t perf_columns_run(int32_t op, const PerfIn &in, uint64_t cap, const void *front, const PerfColumns &pc, hipStream_t st)
+{
+    const uint64_t n = in.n, nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
+    HIP_OK(hipMemsetAsync(pc.shape, 0, PERF_SHAPE_WORDS * 8, st));
+    k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, cap, pc.shape, pc.nranks);
+    LAUNCHED("k_perf_shape");
+    const bool sums = op == MRPDR_SUM || op == MRPDR_AVG;
+    k_perf_shape_verdict<<<1, 64, 0, st>>>(pc.shape, (const uint8_t *)front, sums ? pc.fronts : nullptr, cap);
+    LAUNCHED("k_perf_shape_verdict");
+    k_perf_densify<<<blocks_for(n * cap, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, pc.shape, cap, pc.dense);
+    LAUNCHED("k_perf_densify");
+    FilterIn fin = { (const uint8_t *)in.data_vals, 0, (const uint8_t *)pc.nranks, 4, n, 0, nullptr };
+    WideMulti m = { pc.shape, perf_columns_ws_stride(n), pc.fronts, pc.nodes, (const uint8_t *)pc.dense, in.data_counts };
+    const dim3 wide((uint32_t)nc, (uint32_t)cap), one(1, (uint32_t)cap);
+    if (op == MRPDR_SUM) {
+        k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, m);
+        k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, m);
+        k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, nullptr, nullptr, m);
+    } else if (op == MRPDR_AVG) {
+        k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, m);
+        k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, m);
+        k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, pc.ws, nc, nullptr, nullptr, m);
+    } else {
+        // MIN / MAX: the elements' trees side by side (the summaries' room holds their nodes)
+        const uint32_t tiles = blocks_for(n, FILTER_TILE);
+        const dim3 tg(tiles, (uint32_t)cap);
+        if (op == MRPDR_MIN) {
+            k_perf_minmax_fronts<MRPDR_MIN><<<1, 64, 0, st>>>(pc.shape, (const uint8_t *)front, pc.fronts);
+            k_tree_tile_multi<OP_MINR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)pc.ws, tiles, m);
+            k_tree_top_multi<OP_MINR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)pc.ws, tiles, tiles, nullptr, nullptr, m);
+        } else {
+            k_perf_minmax_fronts<MRPDR_MAX><<<1, 64, 0, st>>>(pc.shape, (const uint8_t *)front, pc.fronts);
+            k_tree_tile_multi<OP_MAXR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)pc.ws, tiles, m);
+            k_tree_top_multi<OP_MAXR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)pc.ws, tiles, tiles, nullptr, nullptr, m);
+        }
+    }
+    LAUNCHED("PerfData column passes");
+    return 1;
 }
 
 extern "C" uint64_t mrpdr_perfdata_scratch_bytes(uint64_t n, uint64_t group, uint64_t out_cap)
@@ -1968,58 +2023,19 @@ extern "C" int32_t mrpdr_wave_perfdata(mrpdr_ctx *c, int32_t op, int32_t type,
         const uint64_t all[1] = { 0 };
         const PerfPlan serial = perf_plan(n, all, 1);
         hipStream_t st = (hipStream_t)stream;
-        // Doubles, SUM / AVG: if every packet carries the same number of elements, end to end, the elements
-        // are strided columns and their chains of roundings are taken by the device-wide exact fold, side
-        // by side; the device finds out (k_perf_shape), and the serial fold below runs only if not.
+        // Doubles: the elements are columns -- in place if every packet carries the same number of them,
+        // end to end, from a dense copy otherwise -- and their chains of roundings are taken by the
+        // device-wide exact fold, side by side; the device finds out which (k_perf_shape), and the serial
+        // fold below runs only if neither applies (a result longer than out_cap).
         if (type == MRPDR_DOUBLE_T && n >= PERF_COLUMNS_MIN && out_cap &&
             out_cap <= PERF_COLUMNS_MAX_CAP && scratch && !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, out_cap)) {
-            uint8_t *p = (uint8_t *)scratch;
-            uint64_t *shape = (uint64_t *)p;                    // [0] regular, [1] k, [2] first, [3] total ranks
-            uint32_t *irregular = (uint32_t *)(p + 32);         p += 64;
-            int32_t *nranks = (int32_t *)p;                     p += up16(4 * n);
-            uint8_t *results = p;                               p += 2 * up16(16 * out_cap);
-            int32_t *oks = (int32_t *)p;                        p += up16(4 * out_cap);
-            void *ws = p;
-            const uint64_t nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
-            HIP_OK(hipMemsetAsync(scratch, 0, 64, st));
-            k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, out_cap, shape, nranks, irregular);
-            LAUNCHED("k_perf_shape");
-            k_perf_shape_verdict<<<1, 64, 0, st>>>(shape, irregular, nullptr, nullptr);
-            LAUNCHED("k_perf_shape_verdict");
-            FilterIn fin = { (const uint8_t *)data->values, 0, (const uint8_t *)nranks, 4, n, 0, nullptr };
-            const WideMulti m = { shape, perf_columns_ws_stride(n), nullptr, nullptr };
-            const dim3 wide((uint32_t)nc, (uint32_t)out_cap), one(1, (uint32_t)out_cap);
-            if (op == MRPDR_SUM) {
-                k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-                k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-                k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
-                LAUNCHED("k_wide_*_multi");
-                k_perf_from_columns<MRPDR_SUM><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
-            } else if (op == MRPDR_AVG) {
-                k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-                k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-                k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, results, oks, m);
-                LAUNCHED("k_wide_*_multi");
-                k_perf_from_columns<MRPDR_AVG><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
-            } else {
-                // MIN / MAX: the elements' trees side by side (the summaries' room holds their nodes)
-                const uint32_t tiles = blocks_for(n, FILTER_TILE);
-                Partial *fronts = (Partial *)(results + up16(16 * out_cap));
-                WideMulti mm = m;
-                const dim3 tg(tiles, (uint32_t)out_cap);
-                if (op == MRPDR_MIN) {
-                    k_tree_tile_multi<OP_MINR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
-                    k_tree_top_multi<OP_MINR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, results, oks, mm);
-                    k_perf_from_columns<MRPDR_MIN><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
-                } else {
-                    k_perf_minmax_fronts<MRPDR_MAX><<<1, 64, 0, st>>>(shape, nullptr, fronts);
-                    mm.fronts = fronts;
-                    k_tree_tile_multi<OP_MAXR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
-                    k_tree_top_multi<OP_MAXR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, results, oks, mm);
-                    k_perf_from_columns<MRPDR_MAX><<<1, MRPDR_TPB, 0, st>>>(shape, results, final);
-                }
-            }
+            const PerfColumns pc = perf_columns(scratch, n, out_cap);
+            if (!perf_columns_run(op, in, out_cap, nullptr, pc, st)) return 0;
+            if (op == MRPDR_SUM) k_perf_from_columns<MRPDR_SUM><<<1, MRPDR_TPB, 0, st>>>(pc.shape, pc.nodes, final);
+            else if (op == MRPDR_AVG) k_perf_from_columns<MRPDR_AVG><<<1, MRPDR_TPB, 0, st>>>(pc.shape, pc.nodes, final);
+            else k_perf_from_columns<MRPDR_MIN><<<1, MRPDR_TPB, 0, st>>>(pc.shape, pc.nodes, final);
             LAUNCHED("k_perf_from_columns");
+            const uint64_t *shape = pc.shape;
             PerfRaw unless_regular = none;
             unless_regular.unless = shape;
             return perf_run_plan(who, c, op, type, in, serial, false, out_cap, final, unless_regular, nullptr, 0, st);
@@ -2061,52 +2077,14 @@ extern "C" int32_t mrpdr_wave_perfdata_partial(mrpdr_ctx *c, int32_t op, int32_t
     PerfPlan plan = perf_plan(n, all, 1);
     if (chained && n >= PERF_COLUMNS_MIN && cap && cap <= PERF_COLUMNS_MAX_CAP && scratch &&
         !((uintptr_t)scratch & 15u) && scratch_bytes >= perf_columns_bytes(n, cap)) {
-        // doubles whose arrays all have one length (and a state in front of the same form): the elements'
-        // chains as strided columns, each continued from the front's accumulator (see mrpdr_wave_perfdata);
-        // the serial fold below runs only if the device finds the wave, or the front, to be of another form
-        uint8_t *p = (uint8_t *)scratch;
-        uint64_t *shape = (uint64_t *)p;
-        uint32_t *irregular = (uint32_t *)(p + 32);         p += 64;
-        int32_t *nranks = (int32_t *)p;                     p += up16(4 * n);
-        Partial *fronts = (Partial *)p;                     p += up16(16 * cap);
-        Partial *nodes = (Partial *)p;                      p += up16(16 * cap);
-        p += up16(4 * cap);
-        void *ws = p;
-        const uint64_t nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
-        HIP_OK(hipMemsetAsync(scratch, 0, 64, st));
-        k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, cap, shape, nranks, irregular);
-        LAUNCHED("k_perf_shape");
-        k_perf_shape_verdict<<<1, 64, 0, st>>>(shape, irregular, (const uint8_t *)front, fronts);
-        LAUNCHED("k_perf_shape_verdict");
-        FilterIn fin = { (const uint8_t *)data->values, 0, (const uint8_t *)nranks, 4, n, 0, nullptr };
-        const WideMulti m = { shape, perf_columns_ws_stride(n), front ? fronts : nullptr, nodes };
-        const dim3 wide((uint32_t)nc, (uint32_t)cap), one(1, (uint32_t)cap);
-        if (op == MRPDR_SUM) {
-            k_wide_sums_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-            k_wide_maps_multi<MRPDR_SUM, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-            k_wide_walk_multi<MRPDR_SUM, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
-        } else if (op == MRPDR_AVG) {
-            k_wide_sums_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-            k_wide_maps_multi<MRPDR_AVG, double><<<wide, WIDE_TPB, 0, st>>>(fin, ws, nc, m);
-            k_wide_walk_multi<MRPDR_AVG, double><<<one, WIDE_TPB, 0, st>>>(fin, ws, nc, nullptr, nullptr, m);
-        } else {
-            const uint32_t tiles = blocks_for(n, FILTER_TILE);
-            WideMulti mm = m;
-            mm.fronts = fronts;                 // (the state in front, or MAX's start value; MIN without a front: absent nodes)
-            const dim3 tg(tiles, (uint32_t)cap);
-            if (op == MRPDR_MIN) {
-                k_perf_minmax_fronts<MRPDR_MIN><<<1, 64, 0, st>>>(shape, (const uint8_t *)front, fronts);
-                k_tree_tile_multi<OP_MINR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
-                k_tree_top_multi<OP_MINR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, nullptr, nullptr, mm);
-            } else {
-                k_perf_minmax_fronts<MRPDR_MAX><<<1, 64, 0, st>>>(shape, (const uint8_t *)front, fronts);
-                k_tree_tile_multi<OP_MAXR, double><<<tg, MRPDR_TPB, 0, st>>>(fin, (Partial *)ws, tiles, mm);
-                k_tree_top_multi<OP_MAXR, double><<<one, MRPDR_TPB, 0, st>>>((const Partial *)ws, tiles, tiles, nullptr, nullptr, mm);
-            }
-        }
-        LAUNCHED("k_wide_*_multi");
-        k_perf_state_from_columns<<<1, 64, 0, st>>>(shape, nodes, (const uint8_t *)front, sp);
+        // doubles: the elements' chains as columns, each continued from the front's accumulator (see
+        // mrpdr_wave_perfdata); the serial fold below runs only if the device finds that front and range
+        // do not fit the bound
+        const PerfColumns pc = perf_columns(scratch, n, cap);
+        if (!perf_columns_run(op, in, cap, front, pc, st)) return 0;
+        k_perf_state_from_columns<<<1, 64, 0, st>>>(pc.shape, pc.nodes, (const uint8_t *)front, sp);
         LAUNCHED("k_perf_state_from_columns");
+        const uint64_t *shape = pc.shape;
         raw.unless = shape;
     }
     if (!chained && n >= PERF_FREE_MIN && perf_lanes(cap) <= 64) {

@@ -284,68 +284,109 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_combine(const uint8_t *state
     }
 }
 
-// ---- one invocation over doubles whose arrays all have one length -------------------------------------
+// ---- one invocation over doubles: the elements' chains side by side ----------------------------------
 // Doubles round at every addition, so one invocation of SUM / AVG is a chain per element -- 131,072
 // dependent steps for a GPU's shard.  The exact chain has a fast form (flatwide.h), and when every
 // packet carries the same number of elements, end to end in the values column (what a stream of one
 // metric's performance data looks like), element u of all packets IS a strided column: the elements'
-// chains are taken by the device-wide fold side by side.  Whether the wave has that form is found out
-// on the device: k_perf_shape checks it and leaves the weights (nrank) as an int32 column; the strided
-// fold runs if it has, the serial k_perfdata if it has not (each looks at shape[0] and leaves at once
+// chains are taken by the device-wide fold side by side (REGULAR).  A wave of another form -- arrays
+// of different lengths, packets without data -- is first copied into that form (RAGGED): a dense
+// n x cap matrix in which a packet's missing elements are +0.0.  Adding +0.0 (or +0.0 times a rank
+// count) changes no bit of a sum that started from +0.0 (such a sum is never -0.0: only -0.0 + -0.0
+// gives it), so the chains over the dense columns are the reference's chains over the packets that do
+// carry the element; MIN / MAX, which have no neutral value (any bits may be data), skip the missing
+// elements by the packets' lengths.  Which form the wave has is found out on the device: k_perf_shape
+// checks it and leaves the weights (nrank, 0 for a packet without data) as an int32 column; the serial
+// k_perfdata runs only where neither form applies (each launch looks at shape[0] and leaves at once
 // when it is not its turn).
-//   shape[0] regular (1 / 0)   shape[1] k   shape[2] first element   shape[3] total ranks
-__global__ __launch_bounds__(MRPDR_TPB) void k_perf_shape(PerfIn in, uint64_t cap, uint64_t *shape, int32_t *nranks, uint32_t *irregular)
+//   shape[0] 0: another path has the wave, 1: REGULAR, 2: RAGGED     shape[1] columns
+//   shape[2] first element of column 0    shape[3] total ranks of these packets
+//   shape[4] longest array of these packets    shape[5] data length of the last packet
+//   shape[6] elements from one packet to the next within a column    shape[7] 1: the columns are in the dense copy
+//   shape[8] (low word) set by any packet that breaks the regular form
+#define PERF_SHAPE_WORDS 16
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_shape(PerfIn in, uint64_t cap, uint64_t *shape, int32_t *nranks)
 {
     const uint64_t i = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
     const uint64_t k = in.data_counts[0], first = in.data_offs[0];
     bool bad = k == 0 || k > cap;
     uint32_t nrank = 0;
+    uint64_t len = 0;
     if (i < in.n) {
-        bad = bad || in.data_counts[i] != k || in.data_offs[i] != first + i * k;
+        len = in.data_counts[i];
+        bad = bad || len != k || in.data_offs[i] != first + i * k;
         int32_t rank = 0;
         if (in.rank_counts[i]) rank = in.rank_vals[in.rank_offs[i]];
-        nrank = (uint32_t)(rank < 0 ? 0 - rank : 1);
+        nrank = len ? (uint32_t)(rank < 0 ? 0 - rank : 1) : 0u;        // a packet without data is nobody's rank
         nranks[i] = (int32_t)nrank;
+        if (i == in.n - 1) shape[5] = len;
     }
-    // the rank total and the verdict: wavefront first, then one atomic each
+    // the rank total, the longest array and the verdict: wavefront first, then one atomic each
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) nrank += __shfl_xor(nrank, d, 64);
+    for (int d = 32; d > 0; d >>= 1) {
+        nrank += __shfl_xor(nrank, d, 64);
+        const uint64_t o = __shfl_xor((unsigned long long)len, d, 64);
+        len = o > len ? o : len;
+    }
     const bool any_bad = __ballot(bad) != 0;
     if ((threadIdx.x & 63u) == 0) {
         atomicAdd(reinterpret_cast<unsigned long long *>(&shape[3]), (unsigned long long)nrank);
-        if (any_bad) atomicOr(irregular, 1u);
+        atomicMax(reinterpret_cast<unsigned long long *>(&shape[4]), (unsigned long long)len);
+        if (any_bad) atomicOr(reinterpret_cast<uint32_t *>(&shape[8]), 1u);
     }
     if (i == 0) { shape[1] = k; shape[2] = first; }
 }
 
 // (a launch of its own: every workgroup of k_perf_shape has to have spoken)
-// front (a state handed over by whoever folded the packets in front, or NULL): the columns go on from it
-// only if it has the same form -- every element covered by every packet so far, k of them; its
-// accumulators then become the columns' front nodes.
-__global__ void k_perf_shape_verdict(uint64_t *shape, const uint32_t *irregular, const uint8_t *front, Partial *fronts)
+// front (a state handed over by whoever folded the packets in front, or NULL): REGULAR columns go on from
+// it only if it has the same form -- every element covered by every packet so far, k of them; RAGGED
+// columns go on from any state that fits the bound.  Its accumulators become the columns' front nodes
+// (fronts, if given: SUM / AVG; MIN / MAX make theirs in k_perf_minmax_fronts).
+__global__ void k_perf_shape_verdict(uint64_t *shape, const uint8_t *front, Partial *fronts, uint64_t cap)
 {
-    bool regular = *irregular == 0;
-    const uint64_t k = shape[1];
-    if (front) {
-        const PerfState h = *reinterpret_cast<const PerfState *>(front);
-        if (h.packets && (h.longest != k || h.last != k)) regular = false;
-        if (regular && threadIdx.x < k) {
-            Partial p;
-            p.bits = h.packets ? reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x] : 0;
-            p.cnt = h.packets ? 0 - h.rank : 0;
-            p.present = h.packets ? 1 : 0;
-            fronts[threadIdx.x] = p;
-        }
+    const uint64_t k = shape[1], first = shape[2], longest = shape[4];
+    bool regular = (uint32_t)shape[8] == 0;
+    PerfState h = { 0, 0, 0, 0, 0 };
+    if (front) h = *reinterpret_cast<const PerfState *>(front);
+    if (!h.packets) { h.longest = 0; h.last = 0; h.rank = 0; }
+    if (h.packets && (h.longest != k || h.last != k)) regular = false;
+    const uint64_t cols = regular ? k : (h.longest > longest ? h.longest : longest);
+    const bool ragged = !regular && longest >= 1 && cols <= cap;
+    __syncthreads();
+    if ((regular || ragged) && fronts && threadIdx.x < cols) {
+        const bool has = threadIdx.x < h.longest;
+        Partial p;
+        p.bits = has ? reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x] : 0;
+        p.cnt = has ? 0 - h.rank : 0;
+        p.present = has ? 1 : 0;
+        fronts[threadIdx.x] = p;
     }
-    if (threadIdx.x == 0) shape[0] = regular ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        shape[0] = regular ? 1u : (ragged ? 2u : 0u);
+        shape[1] = cols;
+        shape[2] = regular ? first : 0;
+        shape[6] = regular ? k : cap;
+        shape[7] = regular ? 0u : 1u;
+    }
+}
+
+// RAGGED: the packets' arrays into the rows of a dense n x cap matrix, +0.0 where a packet has no element
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_densify(PerfIn in, const uint64_t *shape, uint64_t cap, uint64_t *dense)
+{
+    if (shape[0] != 2) return;
+    const uint64_t idx = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    if (idx >= in.n * cap) return;
+    const uint64_t i = idx / cap, u = idx - i * cap;
+    const uint64_t len = in.data_counts[i], off = in.data_offs[i];
+    dense[idx] = u < len ? reinterpret_cast<const uint64_t *>(in.data_vals)[off + u] : 0;
 }
 
 // the columns' nodes behind a packet range into the range's state (struct mrpdr_perf_state + accumulators)
 __global__ void k_perf_state_from_columns(const uint64_t *shape, const Partial *nodes, const uint8_t *front, uint8_t *state)
 {
     if (!shape[0]) return;
-    const uint64_t k = shape[1];
-    if (threadIdx.x < k) reinterpret_cast<uint64_t *>(state + sizeof(PerfState))[threadIdx.x] = nodes[threadIdx.x].bits;
+    const uint64_t cols = shape[1];
+    if (threadIdx.x < cols) reinterpret_cast<uint64_t *>(state + sizeof(PerfState))[threadIdx.x] = nodes[threadIdx.x].bits;
     if (threadIdx.x == 0) {
         uint32_t total = (uint32_t)shape[3];
         if (front) {
@@ -353,26 +394,32 @@ __global__ void k_perf_state_from_columns(const uint64_t *shape, const Partial *
             if (h.packets) total += (uint32_t)(0 - h.rank);
         }
         PerfState out;
-        out.longest = k; out.last = k; out.rank = 0 - (int32_t)total; out.packets = 1; out.reserved = 0;
+        out.longest = cols; out.last = shape[5]; out.rank = 0 - (int32_t)total; out.packets = 1; out.reserved = 0;
         *reinterpret_cast<PerfState *>(state) = out;
     }
 }
 
-// the k results of the strided fold into the output packet
+// the columns' nodes behind a whole wave into the output packet: AVG's one division, over the elements
+// the last packet carries (src/FilterDefinitions.C:1114-1132), by the unsigned rank total
 template <int OP>
-__global__ __launch_bounds__(MRPDR_TPB) void k_perf_from_columns(const uint64_t *shape, const uint8_t *results, PerfOut out)
+__global__ __launch_bounds__(MRPDR_TPB) void k_perf_from_columns(const uint64_t *shape, const Partial *nodes, PerfOut out)
 {
     if (!shape[0]) return;
-    const uint64_t k = shape[1], u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (k > out.stride) {
-        if (u == 0) { atomicOr(out.status, 1u); out.lens[0] = 0; out.ranks[0] = 0 - (int32_t)(uint32_t)shape[3]; }
+    const uint64_t cols = shape[1], last = shape[5], u = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
+    const uint32_t total = (uint32_t)shape[3];
+    if (cols > out.stride) {
+        if (u == 0) { atomicOr(out.status, 1u); out.lens[0] = 0; out.ranks[0] = 0 - (int32_t)total; }
         return;
     }
-    if (u < k) reinterpret_cast<uint64_t *>(out.data)[u] = *reinterpret_cast<const uint64_t *>(results + 16 * u);
-    if (u == 0) { out.lens[0] = k; out.ranks[0] = 0 - (int32_t)(uint32_t)shape[3]; }
+    if (u < cols) {
+        double acc = from_bits<double>(nodes[u].bits);
+        if (OP == MRPDR_AVG && last && u < last) acc = acc / (double)total;
+        reinterpret_cast<double *>(out.data)[u] = acc;
+    }
+    if (u == 0) { out.lens[0] = cols; out.ranks[0] = 0 - (int32_t)total; }
 }
 
-// MIN / MAX of the same regular double waves: the comparison keeps the later operand whenever it is false,
+// MIN / MAX of the same double waves: the comparison keeps the later operand whenever it is false,
 // so a NaN restarts the fold -- the (value, restarted) nodes of OP_MINR / OP_MAXR carry that through a
 // tree, and the elements' trees run side by side (blockIdx.y = element).  tfilter_PerfData's MAX starts
 // from 0 rather than from the first packet (src/FilterDefinitions.C:961-965): that 0 is the front node.
@@ -383,7 +430,29 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_tree_tile_multi(FilterIn in, Part
     if (!wide_multi_column<T>(m, in)) return;
     T vals[FILTER_LEAF];
     int32_t cnts[FILTER_LEAF];
-    const int nvalid = tile_load<T, false>(in, vals, cnts);
+    int nvalid = tile_load<T, false>(in, vals, cnts);
+    if (m.shape[7]) {
+        // RAGGED: only the packets that carry element blockIdx.y take part -- the lane's values move up,
+        // in order, over the ones that do not (selects, no indexed registers)
+        const uint64_t first = (uint64_t)blockIdx.x * FILTER_TILE + (uint64_t)threadIdx.x * FILTER_LEAF;
+        uint64_t lens[FILTER_LEAF];
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) lens[k] = m.row_counts[first + k < in.n ? first + k : in.n - 1];
+        T kept[FILTER_LEAF];
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) kept[k] = T();
+        int nkept = 0;
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) {
+            const bool has = k < nvalid && blockIdx.y < lens[k];
+#pragma unroll
+            for (int j = 0; j < FILTER_LEAF; j++) kept[j] = (has && j == nkept) ? vals[k] : kept[j];
+            nkept += has ? 1 : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < FILTER_LEAF; k++) vals[k] = kept[k];
+        nvalid = nkept;
+    }
 #pragma unroll
     for (int k = 0; k < FILTER_LEAF; k++) cnts[k] = vals[k] != vals[k];
     const Partial out = tile_node<OP, T>(vals, cnts, nvalid, wave_part);
@@ -409,7 +478,7 @@ __global__ void k_perf_minmax_fronts(const uint64_t *shape, const uint8_t *front
     p.bits = 0; p.cnt = 0; p.present = OP == MRPDR_MAX ? 1 : 0;
     if (front) {
         const PerfState h = *reinterpret_cast<const PerfState *>(front);
-        if (h.packets) { p.bits = reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x]; p.present = 1; }
+        if (h.packets && threadIdx.x < h.longest) { p.bits = reinterpret_cast<const uint64_t *>(front + sizeof(PerfState))[threadIdx.x]; p.present = 1; }
     }
     fronts[threadIdx.x] = p;
 }

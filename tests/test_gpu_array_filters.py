@@ -491,3 +491,89 @@ def test_perfdata_double_ranges_relay_the_columns(codec, op):
         assert got[0] == ref[0] and got[1].size == ref[1].size, (n, got, ref)
         assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, ragged_range, got[1][:4], ref[1][:4])
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN, W.TFILTER_MAX])
+@pytest.mark.parametrize("n,kmax", [(8192, 8), (30001, 5), (131072, 8), (20000, 64), (9000, 1)])
+def test_perfdata_double_one_invocation_ragged_waves(codec, op, n, kmax):
+    """Double waves whose arrays have drawn lengths 0 .. kmax (packets without data among them): the
+    elements' chains run over a dense copy in which a missing element is +0.0 -- no bit of a sum changes
+    by it -- and MIN / MAX skip what a packet does not carry.  Against the oracle's serial loop, bits.
+    Variants: the last packet empty (AVG then divides nothing, src/FilterDefinitions.C:1114), the last
+    packet of one element (AVG divides element 0 alone), room for more elements than any packet has, -0.0
+    and NaN data, all-negative data for MAX (whose start value is 0)."""
+    t = O.DOUBLE_T
+    for variant in ("drawn", "last_empty", "last_one", "roomy", "signed_zeros", "negative"):
+        ranks, data = perf_wave(n, t, seed=5 * n + kmax + op, kmax=kmax, aggregated=True)
+        lens, vals = data[0].copy(), data[1].copy()
+        if variant == "last_empty":
+            vals = vals[: vals.size - int(lens[-1])]
+            lens[-1] = 0
+        elif variant == "last_one":
+            vals = np.concatenate([vals[: vals.size - int(lens[-1])], np.array([0.25])])
+            lens[-1] = 1
+        elif variant == "signed_zeros":
+            vals[: vals.size // 2] = 0.0
+            vals[: vals.size // 2: 2] = -0.0                  # sums that sit at zero while elements go missing
+        elif variant == "negative":
+            vals = -np.abs(vals) - 1.0
+        if op in (W.TFILTER_MIN, W.TFILTER_MAX) and variant != "signed_zeros":
+            vals[:: max(1, vals.size // 40)] = np.nan
+        data = (lens, vals)
+        cap = kmax + 3 if variant == "roomy" else kmax
+        ref = O.filter_perfdata(op, t, ranks, data)
+        cols = _perf_cols(codec, t, ranks, data, n)
+        got = _perf_result(t, *codec.filter_perfdata(op, t, cols[0], cols[2], n, group=0, out_cap=cap))
+        assert got[0] == ref[0] and got[1].size == ref[1].size, (variant, got, ref)
+        assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (variant, got[1][:4], ref[1][:4])
+    assert codec.status() == 0
+
+
+def test_perfdata_double_ragged_wave_longer_than_the_bound(codec):
+    """A ragged wave whose longest array does not fit out_cap: the device finds out, no column path takes
+    it, and the call reports as it always has (status bit 1, no elements)."""
+    t, n, kmax = O.DOUBLE_T, 10000, 8
+    ranks, data = perf_wave(n, t, seed=77, kmax=kmax)
+    cols = _perf_cols(codec, t, ranks, data, n)
+    out, out_len, out_rank = codec.filter_perfdata(W.TFILTER_SUM, t, cols[0], cols[2], n, group=0, out_cap=kmax - 2)
+    torch.cuda.synchronize()
+    assert int(out_len.item()) == 0 and codec.status() & 1
+
+
+@pytest.mark.parametrize("op", [W.TFILTER_SUM, W.TFILTER_AVG, W.TFILTER_MIN, W.TFILTER_MAX])
+def test_perfdata_double_ragged_ranges_relay_the_columns(codec, op):
+    """Ragged double waves in ranges: each range's dense columns continue from the state in front, whatever
+    form that has (a regular range behind a ragged one, a ragged one behind a regular one, a range whose
+    packets are all shorter than what the front already holds, a range that is all empty packets)."""
+    t, k = O.DOUBLE_T, 8
+    for n, edges, forms in ((60000, [0, 20000, 40000, 60000], "rgr"), (48000, [0, 16000, 32000, 48000], "grs"),
+                            (40000, [0, 10000, 20000, 20000, 40000], "ge-g"), (36000, [0, 12000, 24000, 36000], "szg")):
+        ranks, _ = perf_wave(n, t, seed=n + op, kmax=k, aggregated=True)
+        lens = np.zeros(n, np.uint64)
+        for (lo, hi), f in zip(zip(edges[:-1], edges[1:]), forms):
+            m = hi - lo
+            if f == "r":   lens[lo:hi] = k                                                            # regular
+            elif f == "g": lens[lo:hi] = splitmix64(n + lo, m) % np.uint64(k + 1)                     # ragged, with empty packets
+            elif f == "s": lens[lo:hi] = splitmix64(n + lo, m) % np.uint64(3) + np.uint64(1)          # short: 1 .. 3 elements
+            elif f == "z": lens[lo:hi] = 0                                                            # nobody carries data
+        vals = ((splitmix64(n + 1, int(lens.sum())) % np.uint64(2000001)).astype(np.float64) - 1e6) * 1e-3
+        if op in (W.TFILTER_MIN, W.TFILTER_MAX):
+            vals = -np.abs(vals)
+            vals[:: 991] = np.nan
+        data = (lens, vals)
+        ref = O.filter_perfdata(op, t, ranks, data)
+        ro = np.zeros(n + 1, np.int64); np.cumsum(ranks[0], out=ro[1:])
+        do = np.zeros(n + 1, np.int64); np.cumsum(lens, out=do[1:])
+        front, states = None, []
+        for lo, hi in zip(edges[:-1], edges[1:]):
+            if hi > lo:
+                cols = _perf_cols(codec, t, (ranks[0][lo:hi], ranks[1][ro[lo]:ro[hi]]), (lens[lo:hi], vals[do[lo]:do[hi]]), hi - lo)
+                front = codec.perfdata_partial(op, t, cols[0], cols[2], hi - lo, k, front)
+            else:
+                empty = W.Column(None, None, None, 0)
+                front = codec.perfdata_partial(op, t, empty, empty, 0, k, front)
+            states.append(front)
+        got = _perf_result(t, *codec.perfdata_combine(op, t, torch.stack(states), k))
+        assert got[0] == ref[0] and got[1].size == ref[1].size, (n, forms, got, ref)
+        assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, forms, got[1][:4], ref[1][:4])
+    assert codec.status() == 0
