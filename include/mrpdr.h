@@ -562,8 +562,12 @@ int32_t mrpdr_wave_array_concat_masked(mrpdr_ctx *ctx, const mrpdr_column *in, u
  *                       start values): given `scratch` of mrpdr_perfdata_scratch_bytes(n, 0,
  *                       out_cap) bytes, waves of 2,048 packets and more are folded as a tree of
  *                       undivided nodes (short chains side by side) instead of one chain over all
- *                       n packets; without scratch, and for doubles (every addition rounds), the
- *                       packets are folded one after the other;
+ *                       n packets.  Doubles round at every addition, so their result IS the chain of
+ *                       each element: with that scratch, waves of 8,192 packets and more whose result
+ *                       has at most 64 elements take the elements' chains side by side through the
+ *                       exact parallel fold the scalar filters use for MRPDR_SHAPE_FLAT (arrays of one
+ *                       length in place, others from a dense copy in the scratch: n * out_cap * 8
+ *                       bytes of it).  Without scratch the packets are folded one after the other;
  *   0 < group < n     : a two-level tree -- nodes of `group` consecutive packets, then one node
  *                       over their outputs (the filter runs at every level, as in an MRNet
  *                       tree: AVG divides and re-weights per level).  Needs `scratch` of
@@ -602,7 +606,8 @@ int32_t mrpdr_wave_perfdata_levels(mrpdr_ctx *ctx, int32_t op, int32_t type,
  *                    state range r left (front), the last state is the wave's; combine takes the LAST
  *                    of the g states it is given.
  * A range without packets (n = 0) hands `front` on (or an empty state).  scratch as for
- * mrpdr_wave_perfdata(group = 0) (optional: integer ranges of 2,048 packets and more use it). */
+ * mrpdr_wave_perfdata(group = 0) (optional: integer ranges of 2,048 packets and more and double ranges
+ * of 8,192 packets and more use it). */
 typedef struct mrpdr_perf_state {
     uint64_t longest;      /* elements that have taken at least one packet */
     uint64_t last;         /* data length of the last packet below (the elements AVG divides) */
