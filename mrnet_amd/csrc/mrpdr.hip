@@ -1760,15 +1760,23 @@ struct PerfColumns {            // the scratch of that path, carved up
 };
 static PerfColumns perf_columns(void *scratch, uint64_t n, uint64_t cap)
 {
-    uint8_t *p = (uint8_t *)scratch;
-    PerfColumns c;
-    c.shape = (uint64_t *)p;    p += PERF_SHAPE_WORDS * 8;
-    c.nranks = (int32_t *)p;    p += up16(4 * n);
-    c.fronts = (Partial *)p;    p += up16(16 * cap);
-    c.nodes = (Partial *)p;     p += up16(16 * cap);
-    c.ws = p;                   p += cap * perf_columns_ws_stride(n);
-    c.dense = (uint64_t *)p;    p += up16(8 * n * cap);
-    c.bytes = (uint64_t)(p - (uint8_t *)scratch);
+    uint64_t at = 0;
+    const uint64_t o_shape = at;    at += PERF_SHAPE_WORDS * 8;
+    const uint64_t o_nranks = at;   at += up16(4 * n);
+    const uint64_t o_fronts = at;   at += up16(16 * cap);
+    const uint64_t o_nodes = at;    at += up16(16 * cap);
+    const uint64_t o_ws = at;       at += cap * perf_columns_ws_stride(n);
+    const uint64_t o_dense = at;    at += up16(8 * n * cap);
+    PerfColumns c = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, at };
+    if (scratch) {
+        uint8_t *p = (uint8_t *)scratch;
+        c.shape = (uint64_t *)(p + o_shape);
+        c.nranks = (int32_t *)(p + o_nranks);
+        c.fronts = (Partial *)(p + o_fronts);
+        c.nodes = (Partial *)(p + o_nodes);
+        c.ws = p + o_ws;
+        c.dense = (uint64_t *)(p + o_dense);
+    }
     return c;
 }
 static uint64_t perf_columns_bytes(uint64_t n, uint64_t out_cap) { return perf_columns(nullptr, n, out_cap).bytes; }
@@ -1785,7 +1793,8 @@ static int32_t perf_columns_run(int32_t op, const PerfIn &in, uint64_t cap, cons
     const bool sums = op == MRPDR_SUM || op == MRPDR_AVG;
     k_perf_shape_verdict<<<1, 64, 0, st>>>(pc.shape, (const uint8_t *)front, sums ? pc.fronts : nullptr, cap);
     LAUNCHED("k_perf_shape_verdict");
-    k_perf_densify<<<blocks_for(n * cap, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, pc.shape, cap, pc.dense);
+    const uint32_t dense_blocks = blocks_for(n * cap, MRPDR_TPB);
+    k_perf_densify<<<dense_blocks < 2048u ? dense_blocks : 2048u, MRPDR_TPB, 0, st>>>(in, pc.shape, cap, pc.dense);
     LAUNCHED("k_perf_densify");
     FilterIn fin = { (const uint8_t *)in.data_vals, 0, (const uint8_t *)pc.nranks, 4, n, 0, nullptr };
     WideMulti m = { pc.shape, perf_columns_ws_stride(n), pc.fronts, pc.nodes, (const uint8_t *)pc.dense, in.data_counts };

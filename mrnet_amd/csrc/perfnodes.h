@@ -374,11 +374,12 @@ __global__ void k_perf_shape_verdict(uint64_t *shape, const uint8_t *front, Part
 __global__ __launch_bounds__(MRPDR_TPB) void k_perf_densify(PerfIn in, const uint64_t *shape, uint64_t cap, uint64_t *dense)
 {
     if (shape[0] != 2) return;
-    const uint64_t idx = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x;
-    if (idx >= in.n * cap) return;
-    const uint64_t i = idx / cap, u = idx - i * cap;
-    const uint64_t len = in.data_counts[i], off = in.data_offs[i];
-    dense[idx] = u < len ? reinterpret_cast<const uint64_t *>(in.data_vals)[off + u] : 0;
+    const uint64_t all = in.n * cap;
+    for (uint64_t idx = (uint64_t)blockIdx.x * MRPDR_TPB + threadIdx.x; idx < all; idx += (uint64_t)gridDim.x * MRPDR_TPB) {
+        const uint64_t i = idx / cap, u = idx - i * cap;
+        const uint64_t len = in.data_counts[i], off = in.data_offs[i];
+        dense[idx] = u < len ? reinterpret_cast<const uint64_t *>(in.data_vals)[off + u] : 0;
+    }
 }
 
 // the columns' nodes behind a packet range into the range's state (struct mrpdr_perf_state + accumulators)
