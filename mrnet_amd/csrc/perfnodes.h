@@ -58,6 +58,10 @@ struct PerfLevel {
     uint32_t raw_mid;           // fuse: the nodes in between are raw
 };
 
+// a packet's length as the records keep it (a length that does not fit is longer than any bound the
+// kernel runs with, and stays so)
+__device__ __forceinline__ uint32_t perf_len32(uint64_t len) { return len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len; }
+
 template <int OP, typename T>
 __global__ __launch_bounds__(MRPDR_TPB) void k_perf_nodes(PerfLevel a)
 {
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_nodes(PerfLevel a)
                 const uint32_t j = lu + (uint32_t)k * W;
                 const bool mine = (uint32_t)k < per_lane && j < m;
                 if ((uint32_t)k < per_lane && j < PERF_CHUNK)
-                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), (uint32_t)len[k], 1u) : make_uint4(0u, 0u, 0u, 0u);
+                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), perf_len32(len[k]), 1u) : make_uint4(0u, 0u, 0u, 0u);
             }
         } else {
             // round trip one: lengths, places, rank counts (unconditional: a record past the node's end
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(MRPDR_TPB) void k_perf_nodes(PerfLevel a)
                 const int32_t *p = (mine && len[k] && rc[k]) ? a.in.rank_vals + ro[k] : reinterpret_cast<const int32_t *>(idle);
                 rank[k] = *p;
                 if ((uint32_t)k < per_lane && j < PERF_CHUNK)
-                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), (uint32_t)len[k], 1u) : make_uint4(0u, 0u, 0u, 0u);
+                    rec[j] = mine ? make_uint4((uint32_t)off[k], (uint32_t)(off[k] >> 32), perf_len32(len[k]), 1u) : make_uint4(0u, 0u, 0u, 0u);
             }
             __syncthreads();
             PERF_STAMP(1);
