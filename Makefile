@@ -33,7 +33,7 @@ $(CTEST): tests/host/test_c_abi.c include/mrpdr.h $(LIB)
 # The plugin run without MRNet: tests/host/test_plugin.cpp implements the Packet methods it calls
 $(PLUGTEST): tests/host/test_plugin.cpp integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h include/mrpdr.h $(LIB)
 	g++ -std=c++11 -O2 -Wall -D__HIP_PLATFORM_AMD__ -Iintegration/buildcheck -Iinclude -I$(ROCM)/include -o $@ \
-		tests/host/test_plugin.cpp -Lmrnet_amd/lib -lmrpdr -L$(ROCM)/lib -lamdhip64 \
+		tests/host/test_plugin.cpp -Lmrnet_amd/lib -lmrpdr -L$(ROCM)/lib -lamdhip64 -lpthread \
 		-Wl,-rpath,'$$ORIGIN/../../mrnet_amd/lib' -Wl,-rpath,$(ROCM)/lib
 
 # One filter call over a wave held by several GPUs, from C++: RCCL for the exchange of the 16-byte nodes

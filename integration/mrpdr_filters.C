@@ -28,7 +28,7 @@
 // Build inside an MRNet tree:
 //     g++ -shared -fPIC integration/mrpdr_filters.C -I<mrnet>/include -I<mrnet>/xplat/include
 //         -I<mrnet>/external/boost/include -I<repo>/include -I/opt/rocm/include
-//         -D__HIP_PLATFORM_AMD__ -L<repo>/mrnet_amd/lib -lmrpdr -L/opt/rocm/lib -lamdhip64
+//         -D__HIP_PLATFORM_AMD__ -L<repo>/mrnet_amd/lib -lmrpdr -L/opt/rocm/lib -lamdhip64 -lpthread
 //         -o libmrpdr_filters.so
 // `make plugin-check` compiles this file against integration/buildcheck/mrnet/MRNet.h, a
 // stand-in that declares only the handful of MRNet names used below (it is a build check of this
@@ -37,6 +37,10 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "mrnet/MRNet.h"
@@ -62,6 +66,79 @@ struct GpuFilterState {
 };
 
 const uint64_t MAX_WAVE = 1u << 22;
+
+// ---- helpers for the gather of large waves ------------------------------------------------------------
+// What a filter does on the host is a walk over the wave's Packet objects, a few dependent cache lines
+// each; from some ten thousand packets on that walk is most of the call (measured: 306 of 316 us at
+// 65,536 packets).  A few threads, kept between waves, take a part of the wave each.  One pool for the
+// whole plugin; a wave that finds it taken (another stream's filter is gathering) walks alone.
+// MRPDR_FILTER_THREADS = 0 .. 16 sets the number of helpers (default 4, never more than the host's
+// other hardware threads).
+class GatherPool {
+public:
+    typedef void (*Part)(void *arg, unsigned part, unsigned parts);
+    static GatherPool &get() { static GatherPool pool; return pool; }
+    unsigned helpers() const { return (unsigned)workers_.size(); }
+    // fn(arg, p, parts) for p = 0 .. parts - 1, part 0 on the calling thread; false: not run at all
+    bool run(Part fn, void *arg)
+    {
+        if (workers_.empty() || !busy_.try_lock()) return false;
+        {
+            std::lock_guard<std::mutex> hold(m_);
+            fn_ = fn; arg_ = arg; pending_ = (int)workers_.size(); gen_++;
+        }
+        wake_.notify_all();
+        fn(arg, 0, (unsigned)workers_.size() + 1);
+        {
+            std::unique_lock<std::mutex> hold(m_);
+            done_.wait(hold, [this] { return pending_ == 0; });
+        }
+        busy_.unlock();
+        return true;
+    }
+private:
+    GatherPool() : fn_(NULL), arg_(NULL), gen_(0), pending_(0), quit_(false)
+    {
+        unsigned want = 4;
+        if (const char *e = getenv("MRPDR_FILTER_THREADS")) want = (unsigned)atoi(e);
+        const unsigned hw = std::thread::hardware_concurrency();
+        if (hw && want > hw - 1) want = hw - 1;
+        if (want > 16) want = 16;
+        for (unsigned k = 0; k < want; k++) workers_.push_back(std::thread(&GatherPool::loop, this, k + 1));
+    }
+    ~GatherPool()
+    {
+        { std::lock_guard<std::mutex> hold(m_); quit_ = true; }
+        wake_.notify_all();
+        for (size_t k = 0; k < workers_.size(); k++) workers_[k].join();
+    }
+    void loop(unsigned part)
+    {
+        unsigned seen = 0;
+        std::unique_lock<std::mutex> hold(m_);
+        for (;;) {
+            wake_.wait(hold, [&] { return quit_ || gen_ != seen; });
+            if (quit_) return;
+            seen = gen_;
+            const Part fn = fn_;
+            void *arg = arg_;
+            const unsigned parts = (unsigned)workers_.size() + 1;
+            hold.unlock();
+            fn(arg, part, parts);
+            hold.lock();
+            if (--pending_ == 0) done_.notify_one();
+        }
+    }
+    std::mutex m_, busy_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> workers_;
+    Part fn_;
+    void *arg_;
+    unsigned gen_;
+    int pending_;
+    bool quit_;
+};
+const size_t GATHER_THREADS_MIN = 8192;          // packets from which the helpers are woken
 
 bool hip_ok(hipError_t e, const char *what)
 {
@@ -130,6 +207,59 @@ bool grow(GpuFilterState *st, size_t n, size_t row)
     return true;
 }
 
+// The gather of a scalar wave (or of packets [n * part / parts, n * (part + 1) / parts) of it):
+// get_Buffer() is the encoded data of a packet (value[, count], no padding) and becomes a row.  A
+// received packet carries its sender's byte order as the last byte of its header (src/Packet.C:96); a
+// packet made on this node has native order and possibly no header yet.
+struct ScalarGather {
+    const std::vector<PacketPtr> *in;
+    uint8_t *rows, *orders;
+    const char *fmt_text;
+    size_t row;
+    uint8_t native;
+    std::atomic<bool> foreign;          // a packet of the other byte order was seen
+    std::atomic<size_t> bad;            // the first packet that is not of the wave's format (n: none)
+};
+
+void gather_scalar_part(void *arg, unsigned part, unsigned parts)
+{
+    ScalarGather &g = *static_cast<ScalarGather *>(arg);
+    const std::vector<PacketPtr> &in = *g.in;
+    const size_t n = in.size(), lo = n * part / parts, hi = n * (part + 1) / parts, row = g.row;
+    bool foreign = false;
+    const char *same_fmt = g.fmt_text;    // the last format pointer found equal: packets that share it are not compared again
+    for (size_t i = lo; i < hi; i++) {
+        // every packet is an object of its own somewhere on the heap: the walk over them is a chain of
+        // cache misses, so the packet objects a few places ahead are asked for now (the pointer alone:
+        // no accessor is called on them, accessors take the packet's lock)
+        if (i + 12 < hi) __builtin_prefetch(in[i + 12].get());
+        const Packet &p = *in[i];
+        const char *pf = p.get_FormatString();
+        const char *buf = p.get_Buffer();
+        if ((pf != same_fmt && strcmp(pf, g.fmt_text) != 0) || p.get_BufferLen() != row || !buf) {
+            size_t seen = g.bad.load();
+            while (i < seen && !g.bad.compare_exchange_weak(seen, i)) { }
+            return;
+        }
+        same_fmt = pf;
+        // rows are 1 to 12 bytes: fixed-size copies (a store or two) instead of a call with a run-time length
+        uint8_t *dst = g.rows + i * row;
+        switch (row) {
+        case 4:  memcpy(dst, buf, 4); break;
+        case 8:  memcpy(dst, buf, 8); break;
+        case 12: memcpy(dst, buf, 12); break;
+        case 2:  memcpy(dst, buf, 2); break;
+        case 1:  *dst = (uint8_t)*buf; break;
+        default: memcpy(dst, buf, row); break;
+        }
+        const char *hdr = p.get_Header();
+        const unsigned hdr_len = p.get_HeaderLen();
+        g.orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : g.native;
+        foreign = foreign || g.orders[i] != g.native;
+    }
+    if (foreign) g.foreign.store(true);
+}
+
 // One wave through TFILTER_<op>.  Nothing is pushed to `out` when the filter has nothing to emit
 // (a format it does not accept, a failure), as the built-ins do after logging.
 void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, void **state)
@@ -151,40 +281,13 @@ void run(int op, const char *name, const std::vector<PacketPtr> &in, std::vector
     const size_t width = (size_t)mrpdr_fmt_field_width(st->fmt, 0);
     const size_t row = (size_t)mrpdr_fmt_fixed_bytes(st->fmt);
     if (!grow(st, n, row)) return;
-    // Gather the wave: get_Buffer() is the encoded data of a packet (value[, count], no padding).
-    // A received packet carries its sender's byte order as the last byte of its header
-    // (src/Packet.C:96); a packet made on this node has native order and possibly no header yet.
-    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
-    bool foreign = false;
-    const char *same_fmt = fmt_text;      // the last format pointer found equal: packets that share it are not compared again
-    for (size_t i = 0; i < n; i++) {
-        // every packet is an object of its own somewhere on the heap: the walk over them is a chain of
-        // cache misses, so the packet objects a few places ahead are asked for now (the pointer alone:
-        // no accessor is called on them, accessors take the packet's lock)
-        if (i + 12 < n) __builtin_prefetch(in[i + 12].get());
-        const Packet &p = *in[i];
-        const char *pf = p.get_FormatString();
-        const char *buf = p.get_Buffer();
-        if ((pf != same_fmt && strcmp(pf, fmt_text) != 0) || p.get_BufferLen() != row || !buf) {
-            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
-            return;
-        }
-        same_fmt = pf;
-        // rows are 1 to 12 bytes: fixed-size copies (a store or two) instead of a call with a run-time length
-        uint8_t *dst = st->h_rows + i * row;
-        switch (row) {
-        case 4:  memcpy(dst, buf, 4); break;
-        case 8:  memcpy(dst, buf, 8); break;
-        case 12: memcpy(dst, buf, 12); break;
-        case 2:  memcpy(dst, buf, 2); break;
-        case 1:  *dst = (uint8_t)*buf; break;
-        default: memcpy(dst, buf, row); break;
-        }
-        const char *hdr = p.get_Header();
-        const unsigned hdr_len = p.get_HeaderLen();
-        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
-        foreign = foreign || st->h_orders[i] != native;
+    ScalarGather job = { &in, st->h_rows, st->h_orders, fmt_text, row, (uint8_t)mrpdr_local_byteorder(), { false }, { n } };
+    if (n < GATHER_THREADS_MIN || !GatherPool::get().run(gather_scalar_part, &job)) gather_scalar_part(&job, 0, 1);
+    if (job.bad.load() < n) {
+        fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, job.bad.load(), fmt_text);
+        return;
     }
+    const bool foreign = job.foreign.load();
     if (!hip_ok(hipMemcpyAsync(st->d_rows, st->h_rows, n * row, hipMemcpyHostToDevice, st->stream), "H2D")) return;
     // The result comes back by itself: the filter's last kernel writes the 16 bytes and then, behind a
     // system-scope fence, the presence flag into pinned memory; this thread presets the flag to
@@ -334,6 +437,71 @@ bool var_grow(VarState *st, size_t n, size_t bytes, int nf, bool strings)
     return true;
 }
 
+// The gather of a wave of array packets, in two walks (pass 0: format, lengths, byte totals per part;
+// pass 1: the copies into the arena, byte orders, offsets), each over packets
+// [n * part / parts, n * (part + 1) / parts).
+struct VarGather {
+    enum { MAX_PARTS = 17 };
+    const std::vector<PacketPtr> *in;
+    const char *fmt_text;
+    uint8_t native;
+    int pass;
+    unsigned parts;                     // of pass 0 (pass 1 must use the same)
+    std::vector<uint64_t> lens;
+    size_t part_bytes[MAX_PARTS];       // pass 0: bytes of each part; then: where each part starts in the arena
+    uint8_t *arena, *orders;
+    uint64_t *offsets, *out_lens;
+    std::atomic<size_t> bad;
+    std::atomic<bool> mixed;            // not every packet has the byte order of packet 0
+};
+
+void gather_var_part(void *arg, unsigned part, unsigned parts)
+{
+    VarGather &g = *static_cast<VarGather *>(arg);
+    const std::vector<PacketPtr> &in = *g.in;
+    const size_t n = in.size(), lo = n * part / parts, hi = n * (part + 1) / parts;
+    if (g.pass == 0) {
+        if (part == 0) g.parts = parts;
+        size_t bytes = 0;
+        const char *same_fmt = g.fmt_text;
+        for (size_t i = lo; i < hi; i++) {
+            if (i + 12 < hi) __builtin_prefetch(in[i + 12].get());
+            const Packet &p = *in[i];
+            const char *pf = p.get_FormatString();
+            if ((pf != same_fmt && strcmp(pf, g.fmt_text) != 0) || !p.get_Buffer()) {
+                size_t seen = g.bad.load();
+                while (i < seen && !g.bad.compare_exchange_weak(seen, i)) { }
+                return;
+            }
+            same_fmt = pf;
+            g.lens[i] = (uint64_t)p.get_BufferLen();
+            bytes += (size_t)g.lens[i];
+        }
+        g.part_bytes[part] = bytes;
+        return;
+    }
+    size_t at = g.part_bytes[part];
+    // the byte order every packet is compared with: packet 0's (a received packet carries its sender's
+    // byte order as the last byte of its header, src/Packet.C:96; a packet made on this node has native
+    // order and possibly no header yet)
+    const char *hdr0 = in[0]->get_Header();
+    const unsigned hdr0_len = in[0]->get_HeaderLen();
+    const uint8_t order0 = (hdr0 && hdr0_len) ? (uint8_t)hdr0[hdr0_len - 1] : g.native;
+    bool mixed = false;
+    for (size_t i = lo; i < hi; i++) {
+        if (i + 12 < hi) __builtin_prefetch(in[i + 12].get());
+        const Packet &p = *in[i];
+        const size_t len = (size_t)g.lens[i];
+        memcpy(g.arena + at, p.get_Buffer(), len);
+        g.offsets[i] = at; g.out_lens[i] = len; at += len;
+        const char *hdr = p.get_Header();
+        const unsigned hdr_len = p.get_HeaderLen();
+        g.orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : g.native;
+        mixed = mixed || g.orders[i] != order0;
+    }
+    if (mixed) g.mixed.store(true);
+}
+
 // The wave into the arena and onto the device, decoded into cols[nf] (every packet with its own
 // sender's byte order).  False: nothing to emit (a message has been printed).
 bool gather_and_decode(const char *name, VarState *st, const std::vector<PacketPtr> &in, int nf, bool strings,
@@ -341,32 +509,36 @@ bool gather_and_decode(const char *name, VarState *st, const std::vector<PacketP
 {
     const size_t n = in.size();
     const char *fmt_text = st->fmt_text;
+    // two walks over the packets, each in parts (helper threads for large waves): lengths and format
+    // first -- the arena is sized by their sum, and a part starts where the parts in front end -- then
+    // the copies
+    VarGather job;
+    job.in = &in; job.fmt_text = fmt_text; job.native = (uint8_t)mrpdr_local_byteorder();
+    job.bad.store(n); job.mixed.store(false);
+    job.lens.resize(n);
+    memset(job.part_bytes, 0, sizeof job.part_bytes);
+    const bool threads = n >= GATHER_THREADS_MIN;
+    job.pass = 0;
+    if (!threads || !GatherPool::get().run(gather_var_part, &job)) gather_var_part(&job, 0, 1);
+    if (job.bad.load() < n) {
+        fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, job.bad.load(), fmt_text);
+        return false;
+    }
     size_t bytes = 0;
-    for (size_t i = 0; i < n; i++) {
-        if (strcmp(in[i]->get_FormatString(), fmt_text) != 0 || !in[i]->get_Buffer()) {
-            fprintf(stderr, "%s: packet %zu of the wave is not a '%s' packet\n", name, i, fmt_text);
-            return false;
-        }
-        bytes += (size_t)in[i]->get_BufferLen();
-    }
+    for (unsigned k = 0; k < VarGather::MAX_PARTS; k++) { const size_t b = job.part_bytes[k]; job.part_bytes[k] = bytes; bytes += b; }
     if (!var_grow(st, n, bytes, nf, strings)) return false;
-    const uint8_t native = (uint8_t)mrpdr_local_byteorder();
-    uint64_t *offsets = st->h_meta, *lens = st->h_meta + n + 1;
-    bool same = true;
-    size_t at = 0;
-    for (size_t i = 0; i < n; i++) {
-        const Packet &p = *in[i];
-        const size_t len = (size_t)p.get_BufferLen();
-        memcpy(st->h_arena + at, p.get_Buffer(), len);
-        offsets[i] = at; lens[i] = len; at += len;
-        // a received packet carries its sender's byte order as the last byte of its header
-        // (src/Packet.C:96); a packet made on this node has native order and possibly no header yet
-        const char *hdr = p.get_Header();
-        const unsigned hdr_len = p.get_HeaderLen();
-        st->h_orders[i] = (hdr && hdr_len) ? (uint8_t)hdr[hdr_len - 1] : native;
-        same = same && st->h_orders[i] == st->h_orders[0];
+    job.arena = st->h_arena; job.orders = st->h_orders; job.offsets = st->h_meta; job.out_lens = st->h_meta + n + 1;
+    job.pass = 1;
+    // (the same number of parts as in the first walk: the parts' starts were added up for it)
+    if (job.parts == 1 || !GatherPool::get().run(gather_var_part, &job)) {
+        if (job.parts != 1) {           // the helpers were there for the first walk and are not now: one part over all
+            memset(job.part_bytes, 0, sizeof job.part_bytes);
+            job.parts = 1;
+        }
+        gather_var_part(&job, 0, 1);
     }
-    offsets[n] = at;
+    const bool same = !job.mixed.load();
+    st->h_meta[n] = bytes;
     uint64_t *d_offsets = st->d_meta, *d_lens = st->d_meta + n + 1;
     if (!hip_ok(hipMemcpyAsync(st->d_arena, st->h_arena, bytes ? bytes : 1, hipMemcpyHostToDevice, st->stream), "H2D") ||
         !hip_ok(hipMemcpyAsync(st->d_meta, st->h_meta, 8 * (2 * n + 1), hipMemcpyHostToDevice, st->stream), "H2D"))

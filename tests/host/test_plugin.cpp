@@ -180,6 +180,35 @@ template <typename T> static void test_type(const char *fmt, uint64_t n, int ord
     }
 }
 
+// A wave with one packet of another format is refused as a whole, as the built-ins assert one format per
+// wave (src/FilterDefinitions.C:104-105) -- wherever the odd packet lies, also in a helper thread's part
+// of a large wave; the stream's state is good for the next, well-formed wave.
+static void test_odd_packet(uint64_t n, uint64_t at)
+{
+    std::vector<PacketPtr> in, out, rev;
+    MRN::TopologyLocalInfo here, *info = &here;
+    PacketPtr params;
+    int32_t want = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const int32_t v = (int32_t)(i * 7u + 1u);
+        const double d = 0.5;
+        const void *f[1] = { i == at ? (const void *)&d : (const void *)&v };
+        in.push_back(received(1073741834u, 100, i == at ? "%lf" : "%d", f, 0));
+        if (i != at) want = (int32_t)((uint32_t)want + (uint32_t)v);
+    }
+    void *state = NULL;
+    mrpdr_Sum(in, out, rev, &state, params, *info);
+    bool ok = out.empty();
+    const int32_t one = 1;
+    const void *f[1] = { &one };
+    in[at] = received(1073741834u, 100, "%d", f, 0);
+    mrpdr_Sum(in, out, rev, &state, params, *info);
+    want = (int32_t)((uint32_t)want + 1u);
+    ok = ok && out.size() == 1 && memcmp(out[0]->get_Buffer(), &want, 4) == 0;
+    release(static_cast<GpuFilterState *>(state));
+    end_SubTest("mrpdr_Sum(%d, " + std::to_string(n) + " packets, packet " + std::to_string(at) + " of another format)", ok);
+}
+
 // ---- mrpdr_ArrayConcat --------------------------------------------------------------------------
 // An array packet as it looks after Message::recv from a sender of byte order `bo`.
 static PacketPtr received_array(const char *fmt, const void *arr, uint64_t len, size_t w, int bo)
@@ -451,6 +480,10 @@ int main(int argc, char **argv)
             test_type<float>("%f", n, mode);
             test_type<double>("%lf", n, mode);
         }
+    test_odd_packet(100, 37);
+    test_odd_packet(70000, 0);
+    test_odd_packet(70000, 33333);
+    test_odd_packet(70000, 69999);
     for (uint64_t n : { (uint64_t)1, (uint64_t)5, (uint64_t)1025, (uint64_t)20000 })
         for (int mode = 0; mode < 3; mode++) {
             test_concat<int32_t>("%ad", n, mode);

@@ -34,14 +34,15 @@ def test_c_abi_program():
 def test_filter_plugin_program():
     """integration/mrpdr_filters.C, the MRNet filter plugin, run without MRNet
     (tests/host/test_plugin.cpp supplies the Packet methods it calls): mrpdr_Sum / Min / Max / Avg over
-    waves of 1 to 70,000 packets, five types, little-endian, big-endian and mixed senders; and mrpdr_ArrayConcat
+    waves of 1 to 70,000 packets (the large ones gathered by the plugin's helper threads), five types,
+    little-endian, big-endian and mixed senders, waves with one packet of another format; and mrpdr_ArrayConcat
     and mrpdr_IntEqClass over waves of numeric and string arrays / of class packets."""
     exe = os.path.join(ROOT, "tests", "host", "test_plugin")
     assert os.path.exists(exe), "build it with `make` (it travels with the tree, prebuilt)"
     r = subprocess.run([exe], capture_output=True, text=True, timeout=200)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "MRNTEST_FAILURE" not in r.stdout
-    assert r.stdout.count("MRNTEST_SUCCESS") == 4 * 3 * 5 * 4 + 1 + 4 * 3 * 6 + 1 + 4 * 3
+    assert r.stdout.count("MRNTEST_SUCCESS") == 4 * 3 * 5 * 4 + 4 + 1 + 4 * 3 * 6 + 1 + 4 * 3
 
 
 def test_rccl_combine_program():
