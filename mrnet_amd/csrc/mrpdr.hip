@@ -1788,7 +1788,8 @@ static int32_t perf_columns_run(int32_t op, const PerfIn &in, uint64_t cap, cons
 {
     const uint64_t n = in.n, nc = (n + WIDE_CHUNK - 1) / WIDE_CHUNK;
     HIP_OK(hipMemsetAsync(pc.shape, 0, PERF_SHAPE_WORDS * 8, st));
-    k_perf_shape<<<blocks_for(n, MRPDR_TPB), MRPDR_TPB, 0, st>>>(in, cap, pc.shape, pc.nranks);
+    const uint32_t shape_blocks = blocks_for(n, MRPDR_TPB);
+    k_perf_shape<<<shape_blocks < PERF_SHAPE_BLOCKS ? shape_blocks : PERF_SHAPE_BLOCKS, MRPDR_TPB, 0, st>>>(in, cap, pc.shape, pc.nranks);
     LAUNCHED("k_perf_shape");
     const bool sums = op == MRPDR_SUM || op == MRPDR_AVG;
     k_perf_shape_verdict<<<1, 64, 0, st>>>(pc.shape, (const uint8_t *)front, sums ? pc.fronts : nullptr, cap);
