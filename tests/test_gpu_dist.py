@@ -216,23 +216,24 @@ def _rccl_worker(rank, world, port, q):
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
-        codec = W.Codec(device=rank, max_packets=1 << 16)
+        codec = W.Codec(device=rank, max_packets=1 << 17)
+        exact = _exact_cases(codec, rank, world)                    # gathered nodes and the relayed chains
         lo, hi = D.shard_range(N, rank, world)
         vals, cnts = _scalar_wave(N)
         rows = np.zeros((hi - lo, 12), np.uint8)
         rows[:, :8] = vals[lo:hi].view(np.uint8).reshape(-1, 8)
         rows[:, 8:] = cnts[lo:hi].view(np.uint8).reshape(-1, 4)
         wire = W.WireWave(codec.to_device(rows.reshape(-1)), hi - lo, None, None, 12)
-        res, ok = D.filter_wire_sharded(codec, W.TFILTER_AVG, W.Format("%lf %d"), wire)    # all_gather over RCCL
+        res, ok = D.filter_wire_sharded(codec, W.TFILTER_AVG, W.Format("%lf %d"), wire)    # send / recv / broadcast over RCCL
         torch.cuda.synchronize()
-        q.put((rank, res.cpu().numpy().copy(), int(ok.item())))
+        q.put((rank, res.cpu().numpy().copy(), int(ok.item()), exact))
     finally:
         dist.destroy_process_group()
 
 
 def test_two_ranks_over_rccl():
-    """The same exchange with the real backend: one rank per GPU, the 20-byte results gathered by
-    RCCL on the device.  Needs two GPUs (the single-GPU box skips it; the two-ranks-one-GPU test
+    """The same exchange with the real backend: one rank per GPU, the 16-byte nodes gathered or
+    relayed by RCCL on the device.  Needs two GPUs (the single-GPU box skips it; the two-ranks-one-GPU test
     above covers the path with gloo)."""
     world = 2
     if torch.cuda.device_count() < world:
@@ -249,6 +250,7 @@ def test_two_ranks_over_rccl():
         assert p.exitcode == 0
     vals, cnts = _scalar_wave(N)
     want = O.filter_flat(O.AVG, O.DOUBLE_T, vals, cnts)        # one reference call over the whole wave
-    for rank, res, ok in got:
+    for rank, res, ok, exact in got:
         assert ok == 1 and res[:8].tobytes() == np.float64(want[0]).tobytes()
         assert int(res[8:12].view(np.int32)[0]) == int(want[1])
+        _check_exact_cases(exact)
