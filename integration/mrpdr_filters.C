@@ -140,6 +140,21 @@ private:
 };
 const size_t GATHER_THREADS_MIN = 8192;          // packets from which the helpers are woken
 
+// a large block moved by the helpers as well (the destination is fresh from malloc: its pages are
+// touched for the first time here, which is most of what such a copy costs)
+struct CopyJob { uint8_t *dst; const uint8_t *src; size_t bytes; };
+void copy_part(void *arg, unsigned part, unsigned parts)
+{
+    const CopyJob &c = *static_cast<const CopyJob *>(arg);
+    const size_t lo = c.bytes / parts * part, hi = part + 1 == parts ? c.bytes : c.bytes / parts * (part + 1);
+    memcpy(c.dst + lo, c.src + lo, hi - lo);
+}
+void copy_in_parts(void *dst, const void *src, size_t bytes)
+{
+    CopyJob job = { static_cast<uint8_t *>(dst), static_cast<const uint8_t *>(src), bytes };
+    if (bytes < ((size_t)1 << 19) || !GatherPool::get().run(copy_part, &job)) memcpy(dst, src, bytes);
+}
+
 bool hip_ok(hipError_t e, const char *what)
 {
     if (e == hipSuccess) return true;
@@ -339,6 +354,10 @@ struct VarState {
     uint64_t   *d_out_meta;            // per output column: counts[1], offs[2]
     uint8_t    *d_scratch;
     size_t      cap_out[3], cap_scratch;
+    // TFILTER_ARRAY_CONCAT: where the concatenation and its element count come back to (pinned)
+    uint8_t    *h_out;
+    uint64_t   *h_total;
+    size_t      cap_h_out, wave_bytes;  // wave_bytes: data bytes of the wave gather_and_decode took last
 };
 
 void release_var(VarState *st)
@@ -347,6 +366,8 @@ void release_var(VarState *st)
     if (st->h_arena) (void)hipHostFree(st->h_arena);
     if (st->h_orders) (void)hipHostFree(st->h_orders);
     if (st->h_meta) (void)hipHostFree(st->h_meta);
+    if (st->h_out) (void)hipHostFree(st->h_out);
+    if (st->h_total) (void)hipHostFree(st->h_total);
     void *dev[] = { st->d_arena, st->d_orders, st->d_meta, st->d_values[0], st->d_values[1], st->d_values[2],
                     st->d_counts[0], st->d_counts[1], st->d_counts[2], st->d_offs[0], st->d_offs[1], st->d_offs[2],
                     st->d_sub_counts, st->d_sub_offs, st->d_ok, st->d_out[0], st->d_out[1], st->d_out[2],
@@ -539,6 +560,7 @@ bool gather_and_decode(const char *name, VarState *st, const std::vector<PacketP
     }
     const bool same = !job.mixed.load();
     st->h_meta[n] = bytes;
+    st->wave_bytes = bytes;
     uint64_t *d_offsets = st->d_meta, *d_lens = st->d_meta + n + 1;
     if (!hip_ok(hipMemcpyAsync(st->d_arena, st->h_arena, bytes ? bytes : 1, hipMemcpyHostToDevice, st->stream), "H2D") ||
         !hip_ok(hipMemcpyAsync(st->d_meta, st->h_meta, 8 * (2 * n + 1), hipMemcpyHostToDevice, st->stream), "H2D"))
@@ -591,17 +613,33 @@ void run_concat(const std::vector<PacketPtr> &in, std::vector<PacketPtr> &out, v
     if (!gather_and_decode(name, st, in, 1, strings, &col)) return;
     // a packet that does not decode adds nothing, as one whose unpack fails (:771-782): its count is 0
     uint64_t total = 0;
-    if (!hip_ok(hipMemcpyAsync(&total, st->d_offs[0] + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
-    if (!device_fine(name, st)) return;
-    if (total > 0xFFFFFFFFull) { fprintf(stderr, "%s: %llu elements do not fit the filter's 32-bit length\n", name, (unsigned long long)total); return; }
     const bool large = fmt_text[1] == 'A';
     void *result = NULL;
     if (!strings) {
+        // One wait for everything: every element takes `width` bytes of the wave at least, so the
+        // concatenation is copied back in that length together with its element count (both into pinned
+        // memory), and what the count says is then moved into the array the output packet will own.
+        const size_t bound = st->wave_bytes / width;
+        if (!st->h_total && !regrow(&st->h_total, 8, true)) return;
+        if (bound * width > st->cap_h_out) {
+            const size_t cap = grown(st->cap_h_out, bound * width, 1 << 16);
+            st->cap_h_out = 0;
+            if (!regrow(&st->h_out, cap, true)) return;
+            st->cap_h_out = cap;
+        }
+        if (!hip_ok(hipMemcpyAsync(st->h_total, st->d_offs[0] + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+        if (bound && !hip_ok(hipMemcpyAsync(st->h_out, st->d_values[0], bound * width, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+        if (!device_fine(name, st)) return;
+        total = *st->h_total;
+        if (total > 0xFFFFFFFFull) { fprintf(stderr, "%s: %llu elements do not fit the filter's 32-bit length\n", name, (unsigned long long)total); return; }
+        if (total > bound) { fprintf(stderr, "%s: %llu elements from %zu bytes\n", name, (unsigned long long)total, st->wave_bytes); return; }
         result = malloc(total ? total * width : 1);
         if (!result) return;
-        if (total && (!hip_ok(hipMemcpyAsync(result, st->d_values[0], total * width, hipMemcpyDeviceToHost, st->stream), "D2H") ||
-                      !hip_ok(hipStreamSynchronize(st->stream), "hipStreamSynchronize"))) { free(result); return; }
+        copy_in_parts(result, st->h_out, total * width);
     } else {
+        if (!hip_ok(hipMemcpyAsync(&total, st->d_offs[0] + n, 8, hipMemcpyDeviceToHost, st->stream), "D2H")) return;
+        if (!device_fine(name, st)) return;
+        if (total > 0xFFFFFFFFull) { fprintf(stderr, "%s: %llu elements do not fit the filter's 32-bit length\n", name, (unsigned long long)total); return; }
         // the strings come back as one block and the places of each; the packet wants one malloc per string
         std::vector<uint64_t> sub_offs(total + 1);
         if (!hip_ok(hipMemcpyAsync(sub_offs.data(), st->d_sub_offs, 8 * (total + 1), hipMemcpyDeviceToHost, st->stream), "D2H") ||
