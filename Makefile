@@ -47,8 +47,25 @@ plugin-check: integration/mrpdr_filters.C integration/buildcheck/mrnet/MRNet.h i
 	g++ -std=c++11 -Wall -Wextra -fPIC -fsyntax-only -D__HIP_PLATFORM_AMD__ -Iintegration/buildcheck -Iinclude \
 		-I$(ROCM)/include integration/mrpdr_filters.C
 
+# The host side of the library and the three host test programs under AddressSanitizer (host code only:
+# -Xarch_host keeps the device code as it is), built with the same clang so that one ASan runtime serves all:
+#   make asan-host && ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 tools/asan/test_plugin
+CLANGBIN = $(ROCM)/lib/llvm/bin
+asan-host:
+	mkdir -p tools/asan
+	$(HIPCC) --offload-arch=$(ARCH) -O1 -g -fPIC -shared -fwrapv -ffp-contract=off -std=c++17 -Xarch_host -fsanitize=address \
+		-Xarch_host -fno-omit-frame-pointer -o tools/asan/libmrpdr.so $(SRC)/mrpdr.hip
+	$(CLANGBIN)/clang -std=c99 -O1 -g -fsanitize=address -D__HIP_PLATFORM_AMD__ -Iinclude -I$(ROCM)/include -o tools/asan/test_c_abi \
+		tests/host/test_c_abi.c -Ltools/asan -lmrpdr -L$(ROCM)/lib -lamdhip64 -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+	$(CLANGBIN)/clang++ -std=c++11 -O1 -g -fsanitize=address -D__HIP_PLATFORM_AMD__ -Iintegration/buildcheck -Iinclude -I$(ROCM)/include \
+		-o tools/asan/test_plugin tests/host/test_plugin.cpp -Ltools/asan -lmrpdr -L$(ROCM)/lib -lamdhip64 -lpthread \
+		-Wl,-rpath,'$$ORIGIN' -Wl,-rpath,$(ROCM)/lib
+	$(HIPCC) -O1 -g -std=c++17 -Xarch_host -fsanitize=address -o tools/asan/test_packet_wave tests/host/test_packet_wave.cpp \
+		-Ltools/asan -lmrpdr -Wl,-rpath,'$$ORIGIN'
+
 clean:
 	rm -f $(LIB) $(HOSTTEST) $(CTEST) $(PLUGTEST) $(RCCLTEST)
+	rm -rf tools/asan
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean plugin-check
+.PHONY: all oracle clean plugin-check asan-host
