@@ -1,6 +1,7 @@
 /* The C ABI from plain C (C99, gcc): what a C back-end library in the style of the reference's
  * src/lightweight/ would write.  One wave of "%d %s %ad" packets is encoded, decoded again,
- * summed and sent through a Message; output in the reference's test-harness style (tests/test_common.C:41-187). */
+ * summed and sent through a Message; a "%f" wave is summed in three ranges; a wave of performance-data
+ * packets goes through tfilter_PerfData; output in the reference's test-harness style (tests/test_common.C:41-187). */
 #include <stddef.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -138,6 +139,75 @@ int main(void)
             ok = ok && hokh[i] == 1 && okh[i] == 1 && sidh[i] == 0x40000010u && tagh[i] == 101 && srch[i] == 7;
         end_SubTest("mrpdr_message_write_frame / mrpdr_message_parse", ok && announced == payload &&
                                                                        !memcmp(v, v2, sizeof v) && !memcmp(arr, arr2, sizeof arr));
+    }
+
+    /* One tfilter_Sum call over a "%f" wave that three GPUs would hold: every range leaves a node, the
+     * chain of additions goes from node to node (mrpdr_wave_filter_partial), the last node is the
+     * result (mrpdr_wave_filter_combine) -- the bits of the loop src/FilterDefinitions.C:148-200 runs. */
+    {
+        enum { M = 40000 };
+        static float x[M];
+        float chain = 0;
+        for (int i = 0; i < M; i++) { x[i] = (float)((i * 2654435761u) >> 8) * 1e-4f - 800.0f; chain = chain + x[i]; }
+        float *xd = to_device(x, sizeof x);
+        mrpdr_node *nodes = to_device(NULL, 3 * sizeof(mrpdr_node));
+        const int edges[4] = { 0, 9000, 9000 + 20000, M };
+        ok = mrpdr_filter_is_chained(MRPDR_SUM, MRPDR_FLOAT_T) == 1 && mrpdr_filter_is_chained(MRPDR_SUM, MRPDR_INT32_T) == 0;
+        for (int r = 0; r < 3; r++)
+            ok = ok && mrpdr_wave_filter_partial(ctx, MRPDR_SUM, MRPDR_FLOAT_T, xd + edges[r], 4, NULL, 0,
+                                                 (uint64_t)(edges[r + 1] - edges[r]), 0, r ? nodes + r - 1 : NULL, nodes + r, NULL);
+        ok = ok && mrpdr_wave_filter_combine(ctx, MRPDR_SUM, MRPDR_FLOAT_T, nodes, 3, res, rok, NULL);
+        float got = 0;
+        hipMemcpy(&got, res, 4, hipMemcpyDeviceToHost);
+        hipMemcpy(&present, rok, 4, hipMemcpyDeviceToHost);
+        end_SubTest("mrpdr_wave_filter_partial / mrpdr_wave_filter_combine", ok && present == 1 && !memcmp(&got, &chain, 4));
+    }
+
+    /* tfilter_PerfData, TFILTER_AVG over doubles, one invocation over 10,000 packets whose arrays have
+     * 0 .. 8 elements (src/FilterDefinitions.C:984-1132): packets without data are nobody's rank, every
+     * element is a chain of additions over the packets that carry it, the elements the LAST packet
+     * carries are divided by the rank total. */
+    {
+        enum { P = 10000, K = 8 };
+        static int32_t rank[P];
+        static uint64_t one[P], roffs[P + 1], dcnt[P], doffs[P + 1];
+        static double dv[P * K], acc[K];
+        uint64_t at = 0, longest = 0;
+        unsigned total = 0;
+        for (int i = 0; i < P; i++) {
+            rank[i] = (i % 5 == 0) ? -(1 + i % 3) : i;
+            one[i] = 1; roffs[i] = (uint64_t)i;
+            dcnt[i] = (uint64_t)((i * 7 + 3) % (K + 1)); doffs[i] = at;
+            if (i == P - 1) dcnt[i] = 3;
+            const int nrank = rank[i] < 0 ? -rank[i] : 1;
+            if (dcnt[i]) total += (unsigned)nrank;
+            if (dcnt[i] > longest) longest = dcnt[i];
+            for (uint64_t u = 0; u < dcnt[i]; u++) {
+                double v = 1e-3 + 1e-7 * (double)((i * 31 + (int)u * 17) % 1000);
+                dv[at + u] = v;
+                v *= nrank;
+                acc[u] += v;
+            }
+            at += dcnt[i];
+        }
+        roffs[P] = P; doffs[P] = at;
+        for (uint64_t u = 0; u < dcnt[P - 1]; u++) acc[u] /= total;
+        mrpdr_column rk, da;
+        memset(&rk, 0, sizeof rk); memset(&da, 0, sizeof da);
+        rk.values = to_device(rank, sizeof rank); rk.counts = to_device(one, sizeof one); rk.offs = to_device(roffs, sizeof roffs); rk.capacity = P;
+        da.values = to_device(dv, 8 * (at ? at : 1)); da.counts = to_device(dcnt, sizeof dcnt); da.offs = to_device(doffs, sizeof doffs); da.capacity = at;
+        const uint64_t need = mrpdr_perfdata_scratch_bytes(P, 0, K);
+        void *scratch = to_device(NULL, need);
+        double *outd = to_device(NULL, 8 * K);
+        uint64_t *outl = to_device(NULL, 8), len = 0;
+        int32_t *outr = to_device(NULL, 4), orank = 0;
+        static double gotd[K];
+        ok = mrpdr_wave_perfdata(ctx, MRPDR_AVG, MRPDR_DOUBLE_T, &rk, &da, P, 0, outd, K, outl, outr, scratch, need, NULL);
+        hipMemcpy(gotd, outd, sizeof gotd, hipMemcpyDeviceToHost);
+        hipMemcpy(&len, outl, 8, hipMemcpyDeviceToHost);
+        hipMemcpy(&orank, outr, 4, hipMemcpyDeviceToHost);
+        end_SubTest("mrpdr_wave_perfdata(MRPDR_AVG, doubles, ragged arrays)", ok && need > 0 && len == longest && orank == -(int32_t)total &&
+                                                                             !memcmp(gotd, acc, 8 * (size_t)longest));
     }
 
     uint32_t status = 1;

@@ -28,7 +28,7 @@ def test_c_abi_program():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     print(r.stdout[-3000:], r.stderr[-2000:])
     assert r.returncode == 0 and "MRNTEST_FAILURE" not in r.stdout
-    assert r.stdout.count("MRNTEST_SUCCESS") == 6
+    assert r.stdout.count("MRNTEST_SUCCESS") == 8
 
 
 def test_filter_plugin_program():
