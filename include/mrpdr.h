@@ -481,6 +481,13 @@ int32_t mrpdr_wave_filter_partial(mrpdr_ctx *ctx, int32_t op, int32_t type,
                                   const void *counts, uint64_t count_stride,
                                   uint64_t n, int32_t swap,
                                   const mrpdr_node *front, mrpdr_node *node, void *stream);
+/* the same for a range whose packets come from senders of both byte orders (byteorders[i] as in
+ * mrpdr_wave_filter_mixed: Packet::decode_pdr_data decodes every packet with its own, src/Packet.C:118) */
+int32_t mrpdr_wave_filter_partial_mixed(mrpdr_ctx *ctx, int32_t op, int32_t type,
+                                        const void *values, uint64_t value_stride,
+                                        const void *counts, uint64_t count_stride,
+                                        uint64_t n, const uint8_t *byteorders,
+                                        const mrpdr_node *front, mrpdr_node *node, void *stream);
 int32_t mrpdr_wave_filter_combine(mrpdr_ctx *ctx, int32_t op, int32_t type,
                                   const mrpdr_node *nodes, uint64_t g,
                                   void *result, int32_t *result_ok, void *stream);

@@ -25,7 +25,7 @@ SYMBOLS = (
     "mrpdr_message_preamble_bytes", "mrpdr_message_write_preamble", "mrpdr_message_parse_sizes",
     "mrpdr_message_write_frame", "mrpdr_message_parse",
     "mrpdr_wave_filter", "mrpdr_filter_is_chained", "mrpdr_wave_filter_partial", "mrpdr_wave_filter_combine",
-    "mrpdr_wave_decode_filter", "mrpdr_wave_filter_mixed", "mrpdr_wave_filter_noalloc", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
+    "mrpdr_wave_decode_filter", "mrpdr_wave_filter_mixed", "mrpdr_wave_filter_partial_mixed", "mrpdr_wave_filter_noalloc", "mrpdr_wave_filter_stats", "mrpdr_wave_array_concat", "mrpdr_wave_array_concat_masked", "mrpdr_perfdata_scratch_bytes", "mrpdr_wave_perfdata",
     "mrpdr_perfdata_levels_scratch_bytes", "mrpdr_wave_perfdata_levels", "mrpdr_perfdata_state_bytes",
     "mrpdr_perfdata_is_chained", "mrpdr_wave_perfdata_partial", "mrpdr_wave_perfdata_combine",
     "mrpdr_eqclass_scratch_bytes", "mrpdr_wave_int_eq_class",
@@ -110,6 +110,7 @@ def load():
         "mrpdr_wave_filter": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
         "mrpdr_filter_is_chained": (i32, [i32, i32]),
         "mrpdr_wave_filter_partial": (i32, [vp, i32, i32, vp, u64, vp, u64, u64, i32, vp, vp, vp]),
+        "mrpdr_wave_filter_partial_mixed": (i32, [vp, i32, i32, vp, u64, vp, u64, u64, vp, vp, vp, vp]),
         "mrpdr_wave_filter_combine": (i32, [vp, i32, i32, vp, u64, vp, vp, vp]),
         "mrpdr_wave_filter_mixed": (i32, [vp, i32, i32, i32, vp, u64, vp, u64, u64, vp, vp, vp, vp]),
         "mrpdr_wave_decode_filter": (i32, [vp, vp, C.POINTER(Wire), u64, i32, C.POINTER(Column), vp, i32, i32, vp, vp, vp]),

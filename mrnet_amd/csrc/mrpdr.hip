@@ -1427,6 +1427,20 @@ extern "C" int32_t mrpdr_wave_filter_partial(mrpdr_ctx *c, int32_t op, int32_t t
                            nullptr, nullptr, nullptr, stream, FilterLink{ (const Partial *)front, (Partial *)node });
 }
 
+extern "C" int32_t mrpdr_wave_filter_partial_mixed(mrpdr_ctx *c, int32_t op, int32_t type,
+                                                   const void *values, uint64_t value_stride,
+                                                   const void *counts, uint64_t count_stride,
+                                                   uint64_t n, const uint8_t *byteorders,
+                                                   const mrpdr_node *front, mrpdr_node *node, void *stream)
+{
+    if (!ctx_ready("mrpdr_wave_filter_partial_mixed", c)) return 0;
+    if (n > c->max_packets) return fail("mrpdr_wave_filter_partial_mixed: n exceeds the ctx limit");
+    if (!node) return fail("mrpdr_wave_filter_partial_mixed: NULL node");
+    if (n && !byteorders) return fail("mrpdr_wave_filter_partial_mixed: NULL byteorders");
+    return filter_dispatch(ctx_filter_ws(c), op, type, MRPDR_SHAPE_FLAT, values, value_stride, counts, count_stride, n, 0,
+                           n ? byteorders : nullptr, nullptr, nullptr, stream, FilterLink{ (const Partial *)front, (Partial *)node });
+}
+
 extern "C" int32_t mrpdr_wave_filter_combine(mrpdr_ctx *c, int32_t op, int32_t type, const mrpdr_node *nodes, uint64_t g,
                                              void *result, int32_t *result_ok, void *stream)
 {

@@ -620,6 +620,11 @@ class Codec:
         """The 16-byte node of a packet range (struct mrpdr_node as a uint8[16] device tensor);
         front: the node of the packets in front of the range, or None."""
         node = self.empty(16, torch.uint8) if node is None else node
+        if isinstance(swap, torch.Tensor):        # one sender byte order per packet (uint8 device tensor)
+            _check(self._lib.mrpdr_wave_filter_partial_mixed(self.handle, op, int(dtype), values_ptr, value_stride, counts_ptr,
+                                                             count_stride, n, _ptr(swap), _ptr(front), _ptr(node), _stream()),
+                   "mrpdr_wave_filter_partial_mixed")
+            return node
         _check(self._lib.mrpdr_wave_filter_partial(self.handle, op, int(dtype), values_ptr, value_stride, counts_ptr,
                                                    count_stride, n, swap, _ptr(front), _ptr(node), _stream()),
                "mrpdr_wave_filter_partial")

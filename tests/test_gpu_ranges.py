@@ -30,21 +30,28 @@ def _rows(vals, cnt):
     return rows, stride
 
 
-def ranged(codec, op, t, vals, cnt, edges, swap=False, always_front=False):
-    """Nodes of the ranges [edges[r], edges[r+1]) as G ranks would produce them, then the combine."""
+def ranged(codec, op, t, vals, cnt, edges, swap=False, always_front=False, mixed=False):
+    """Nodes of the ranges [edges[r], edges[r+1]) as G ranks would produce them, then the combine.
+    mixed: every third packet comes from a sender of the other byte order (one order per packet)."""
     rows, stride = _rows(vals, cnt)
-    if swap:
-        w = vals.dtype.itemsize
-        rows[:, :w] = rows[:, :w][:, ::-1]
+    w = vals.dtype.itemsize
+    orders = None
+    if swap or mixed:
+        sel = slice(None) if swap else slice(1, None, 3)
+        rows[sel, :w] = rows[sel, :w][:, ::-1]
         if cnt is not None:
-            rows[:, w:] = rows[:, w:][:, ::-1]
+            rows[sel, w:] = rows[sel, w:][:, ::-1]
+        if mixed:
+            oh = np.zeros(max(1, vals.size), np.uint8)
+            oh[1::3] = 1
+            orders = codec.to_device(oh)
     dev = codec.to_device(rows.reshape(-1)) if rows.size else codec.empty(16, torch.uint8)
-    base, w = dev.data_ptr(), vals.dtype.itemsize
+    base = dev.data_ptr()
     chained = codec.is_chained(op, t)
     nodes, front = [], None
     for lo, hi in zip(edges[:-1], edges[1:]):
         node = codec.filter_partial_raw(op, t, base + lo * stride, stride, base + lo * stride + w, stride, hi - lo,
-                                        int(swap), front if (chained or always_front) else None)
+                                        orders[lo:] if mixed else int(swap), front if (chained or always_front) else None)
         nodes.append(node)
         front = node
     if chained or always_front:
@@ -86,8 +93,9 @@ def test_ranges_equal_one_flat_call(codec, tok, t, dt, opname, op):
         # ragged: empty ranges at both ends and in the middle
         cut = sorted(int(x) for x in splitmix64(n, 5) % np.uint64(n + 1))
         check(codec, op, t, dt, vals, cnt, [0, 0] + cut + [n, n], (tok, opname, n, "ragged"))
-        # a sender of the other byte order
+        # a sender of the other byte order; senders of both (mrpdr_wave_filter_partial_mixed)
         check(codec, op, t, dt, vals, cnt, even_edges(n, 2), (tok, opname, n, "swapped"), swap=True)
+        check(codec, op, t, dt, vals, cnt, even_edges(n, 3), (tok, opname, n, "mixed"), mixed=True)
 
 
 @pytest.mark.parametrize("fmt,t,dt,op", [
