@@ -577,3 +577,33 @@ def test_perfdata_double_ragged_ranges_relay_the_columns(codec, op):
         assert got[0] == ref[0] and got[1].size == ref[1].size, (n, forms, got, ref)
         assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (n, forms, got[1][:4], ref[1][:4])
     assert codec.status() == 0
+
+
+@pytest.mark.parametrize("t,op", [(O.DOUBLE_T, W.TFILTER_AVG), (O.INT64_T, W.TFILTER_AVG), (O.DOUBLE_T, W.TFILTER_MIN),
+                                  (O.DOUBLE_T, W.TFILTER_SUM)])
+def test_perfdata_full_size_wave_in_8_ranges(codec, t, op):
+    """The performance-data configuration at its full size: 1,048,576 packets of eight-element arrays held
+    as 8 ranges of 131,072 (one per GPU), every range folded into a state (doubles relayed through the
+    elements' exact chains, integers gathered), against ONE oracle invocation over all packets.  Filter
+    times as the benchmark draws them (normal around 1e-3), a NaN now and then for MIN."""
+    n, k, g = 1 << 20, 8, 8
+    rng = np.random.default_rng(2026)
+    vals = rng.normal(1e-3, 1e-4, n * k)
+    if t == O.INT64_T:
+        vals = (vals * 1e9).astype(np.int64)
+    elif op == W.TFILTER_MIN:
+        vals[:: 100003] = np.nan
+    lens = np.full(n, k, np.uint64)
+    ranks = (np.ones(n, np.uint64), np.arange(n, dtype=np.int32))
+    ref = O.filter_perfdata(op, t, ranks, (lens, vals))
+    chained = codec.perfdata_is_chained(op, t)
+    states, front = [], None
+    for r in range(g):
+        lo, hi = r * n // g, (r + 1) * n // g
+        cols = _perf_cols(codec, t, (ranks[0][lo:hi], ranks[1][lo:hi]), (lens[lo:hi], vals[lo * k:hi * k]), hi - lo)
+        front = codec.perfdata_partial(op, t, cols[0], cols[2], hi - lo, k, front if chained else None)
+        states.append(front)
+    got = _perf_result(t, *codec.perfdata_combine(op, t, torch.stack(states), k))
+    assert got[0] == ref[0] == -n and got[1].size == ref[1].size == k
+    assert np.array_equal(got[1].view(np.uint64), ref[1].view(np.uint64)), (got[1][:4], ref[1][:4])
+    assert codec.status() == 0
