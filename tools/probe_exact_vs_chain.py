@@ -38,3 +38,20 @@ for dt, ty in ((torch.float32, W.DataType.FLOAT_T), (torch.float64, W.DataType.D
         b, rb = timed(v, ty, W.SHAPE_FLAT_SERIAL)
         print("%-8s %-12s exact fold %7.1f us   plain chain %7.1f us   %+5.1f %%   %s" % (str(dt)[6:], name, a, b, 100.0 * (a - b) / b,
                                                                                   "same bits" if ra == rb else "DIFFERENT"), flush=True)
+
+# every kind of data the parity tests draw (tests/test_gpu_flat_scan.py), the same comparison
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np                                                     # noqa: E402
+from test_gpu_flat_scan import datasets                                # noqa: E402
+worst = {}
+for dt, ty, npdt in ((torch.float32, W.DataType.FLOAT_T, np.float32), (torch.float64, W.DataType.DOUBLE_T, np.float64)):
+    for name, host in datasets(npdt, n, 7).items():
+        v = torch.from_numpy(host.copy()).to(dev)
+        a, ra = timed(v, ty, W.SHAPE_FLAT)
+        b, rb = timed(v, ty, W.SHAPE_FLAT_SERIAL)
+        same = ra == rb or (np.isnan(np.frombuffer(ra[:v.element_size()], npdt)[0]) and np.isnan(np.frombuffer(rb[:v.element_size()], npdt)[0]))
+        pct = 100.0 * (a - b) / b
+        worst[str(dt)[6:]] = max(worst.get(str(dt)[6:], -100.0), pct)
+        print("%-8s %-20s exact fold %7.1f us   plain chain %7.1f us   %+5.1f %%   %s" % (str(dt)[6:], name, a, b, pct,
+                                                                                          "same bits" if same else "DIFFERENT"), flush=True)
+print("worst against the chain:", {k: "%+.1f %%" % v for k, v in worst.items()})
