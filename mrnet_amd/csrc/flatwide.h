@@ -73,6 +73,11 @@ struct WideHead { int32_t e0; uint32_t bad; };
 #define WIDE_ALL_BAD ((1u << (4 + WIDE_K * WIDE_SUBS)) - 1u)
 #define WIDE_SUB_BITS (WIDE_ALL_BAD & ~15u)
 __host__ __device__ constexpr uint32_t wide_bad_sub(int cand, uint32_t w) { return 1u << (4 + cand * WIDE_SUBS + (int)w); }
+// bit WIDE_SKIP_SHIFT + w: sub-chunk w will probably not go in one step (the walk's own test on the rough
+// sum in front of it fails, with a margin): the walk adds it plainly without looking at its summaries.
+// Like WIDE_HINT a guess that costs or saves time only.
+#define WIDE_SKIP_SHIFT (4 + WIDE_K * WIDE_SUBS)
+static_assert(WIDE_SKIP_SHIFT + WIDE_SUBS <= 31 && WIDE_K == 3, "head.bad holds the skip bits below WIDE_HINT; the walk ands three candidates' bits");
 __host__ __device__ constexpr uint32_t wide_bad_all_of(int cand) { return (1u << cand) | (((1u << WIDE_SUBS) - 1u) << (4 + cand * WIDE_SUBS)); }
 
 // Workspace of a wave of n packets (16-byte aligned): chunk sums, chunk counts, heads, summaries.
@@ -232,26 +237,46 @@ __device__ __forceinline__ void wide_maps_body(const FilterIn &in, void *ws_base
     for (uint64_t j = t; j < c; j += WIDE_TPB) a += ws.sums[j];
     a = wide_block_sum(a, s_part);                              // (its barriers are behind s_bad = 0)
     a += (double)chain_start<T>(link);                          // (a range of a wave: the sum the packets in front left)
+    // The candidates are chosen per sub-chunk, from the rough sum in front of THAT sub-chunk: where the
+    // sum moves by several binades inside a chunk (an excursion and its way back, zero-mean data near
+    // zero, the first chunk of every wave) the sub-chunks behind the move then have summaries for the
+    // exponents the sum really has there.  A slot of the chunk's own summary holds only where all four
+    // sub-chunks agree on the slot's exponent (wide_then), which they do unless the rough sum changes its
+    // binade inside the chunk -- and then the chunk is opened anyway.
+    __shared__ double s_wsum[WIDE_SUBS];
+    T x[WIDE_EPL];
+    double mine = 0;
+#pragma unroll
+    for (int k = 0; k < WIDE_EPL; k++) { x[k] = wide_value_of<OP, T>(in, raw[k]); mine += (double)x[k]; }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane == 0) s_wsum[wave] = mine;
+    __syncthreads();
+    double aw = a;
+    for (uint32_t w = 0; w < wave; w++) aw += s_wsum[w];
     WideHead head;
-    head.e0 = 0; head.bad = WIDE_ALL_BAD;
-    uint64_t abits;
-    __builtin_memcpy(&abits, &a, 8);
-    const int aef = (int)((abits >> 52) & 0x7ff);
-    if (whole && aef != 0 && aef != 0x7ff) {
-        head.e0 = aef - 1023 - 1;
-        head.bad = 0;
-        for (int k = 0; k < WIDE_K; k++) {
-            const int e = head.e0 + k;
-            if (e < 1 - G::BIAS || e > G::EMASK - 1 - G::BIAS) head.bad |= wide_bad_all_of(k);     // not a normal number of T
+    head.e0 = 0; head.bad = 0;
+    int e0w = 0;
+    uint32_t badw = WIDE_CHUNK_BITS;                             // bit k: this sub-chunk has no candidate k
+    {
+        uint64_t bits;
+        __builtin_memcpy(&bits, &aw, 8);
+        const int ef = (int)((bits >> 52) & 0x7ff);
+        if (whole && ef != 0 && ef != 0x7ff) {
+            e0w = ef - 1023 - 1;
+            badw = 0;
+            for (int k = 0; k < WIDE_K; k++) {
+                const int e = e0w + k;
+                if (e < 1 - G::BIAS || e > G::EMASK - 1 - G::BIAS) badw |= 1u << k;     // not a normal number of T
+            }
         }
+        __builtin_memcpy(&bits, &a, 8);
+        head.e0 = (int)((bits >> 52) & 0x7ff) - 1023 - 1;      // (sub-chunk 0's: what the hint below is computed for)
     }
-    if ((head.bad & WIDE_CHUNK_BITS) != WIDE_CHUNK_BITS) {
+    if (badw != WIDE_CHUNK_BITS) {
         // The candidates side by side, not one after the other: three independent chains of shuffles.
         // (A candidate already marked bad is computed as well and not looked at.)  Every wavefront
         // sums up its own 256 packets, relative to the first of them.
-        T x[WIDE_EPL];
-#pragma unroll
-        for (int k = 0; k < WIDE_EPL; k++) x[k] = wide_value_of<OP, T>(in, raw[k]);
         GridStep<T> st[WIDE_K][WIDE_EPL];
         GridMap<S> inc[WIDE_K], exc[WIDE_K];
         uint32_t cross = 0;
@@ -261,7 +286,7 @@ __device__ __forceinline__ void wide_maps_body(const FilterIn &in, void *ws_base
             f.a0 = f.a1 = 0;
 #pragma unroll
             for (int k = 0; k < WIDE_EPL; k++) {
-                st[cand][k] = grid_step<T>(x[k], head.e0 + cand);
+                st[cand][k] = grid_step<T>(x[k], e0w + cand);
                 cross |= st[cand][k].cross ? 1u << cand : 0u;
                 GridMap<S> g;
                 g.a0 = st[cand][k].step[0]; g.a1 = st[cand][k].step[1];
@@ -310,10 +335,9 @@ __device__ __forceinline__ void wide_maps_body(const FilterIn &in, void *ws_base
                 }
             }
         }
-        uint32_t bad = 0;
 #pragma unroll
         for (int cand = 0; cand < WIDE_K; cand++) {
-            if (__ballot((cross >> cand) & 1u) != 0) bad |= (1u << cand) | wide_bad_sub(cand, wave);
+            if (__ballot((cross >> cand) & 1u) != 0) badw |= 1u << cand;
         }
         if (lane == 63) {
 #pragma unroll
@@ -322,42 +346,61 @@ __device__ __forceinline__ void wide_maps_body(const FilterIn &in, void *ws_base
                 w.of[0].step = inc[cand].a0; w.of[1].step = inc[cand].a1;
                 w.of[0].lo = lo[cand][0]; w.of[1].lo = lo[cand][1];
                 w.of[0].hi = hi[cand][0]; w.of[1].hi = hi[cand][1];
-                w.of[0].e = w.of[1].e = ((head.bad | bad) >> cand) & 1u ? WIDE_NO_E(S) : (S)(head.e0 + cand);
+                w.of[0].e = w.of[1].e = (badw >> cand) & 1u ? WIDE_NO_E(S) : (S)(e0w + cand);
                 s_sub[cand * WIDE_SUBS + wave] = w;
             }
-            if (bad) atomicOr(&s_bad, bad);
-        }
-        __syncthreads();
-        if (t < WIDE_K * WIDE_SUBS) ws.subs[c * (WIDE_K * WIDE_SUBS) + t] = s_sub[t];
-        if (t < WIDE_K) {
-            // (thread `cand` puts candidate `cand`'s sub-chunks together)
-            WideSum<S> out = s_sub[t * WIDE_SUBS];
-            for (uint32_t w = 1; w < WIDE_SUBS; w++) out = wide_then<T>(out, s_sub[t * WIDE_SUBS + w]);
-            ws.maps[c * WIDE_K + t] = out;
-            if (t == 1) {
-                // Is the walk likely to open this chunk?  Candidate 1 is the exponent of the rough sum
-                // in front: the walk's own test on that sum, with a margin for how far the exact chain
-                // may be from it.  (Only a hint: the walk loads hinted chunks ahead of time.)
-                bool hint = ((head.bad | s_bad) & 2u) != 0;
-                if (!hint) {
-                    const S sa = (S)scalbn(a, G::MANT - (head.e0 + 1));
-                    const S margin = (S)1 << (G::MANT - 8);
-                    for (int p = 0; p < 2; p++) hint = hint || !wide_inside<T>(sa + out.of[p].lo, sa + out.of[p].hi, margin);
-                }
-                if (hint) atomicOr(&s_bad, WIDE_HINT);
+            // Will the walk take this sub-chunk in one step?  Slot 1 is the exponent of the rough sum in
+            // front of it: the walk's test on that sum, with a margin for how far the exact chain may be
+            // from it.  A sub-chunk that fails it is not worth the walk's look (which costs what some 90
+            // additions cost): it is marked, and added plainly.
+            bool skip = (badw & 2u) != 0;
+            if (!skip) {
+                const S sa = (S)scalbn(aw, G::MANT - (e0w + 1));
+                const S margin = (S)1 << (G::MANT - 8);
+                for (int p = 0; p < 2; p++) skip = skip || !wide_inside<T>(sa + lo[1][p], sa + hi[1][p], margin);
             }
+            if (skip) atomicOr(&s_bad, 1u << (WIDE_SKIP_SHIFT + wave));
         }
-        __syncthreads();
-        head.bad |= s_bad;
-    }
-    else if (t < WIDE_K * (1 + WIDE_SUBS)) {
-        // no candidate at all (the sum in front is zero or not finite, the last, partial chunk): the
-        // walk reads the summaries before anything else, so they have to say so themselves
+    } else if (lane == 63) {
+        // no candidate at all for this sub-chunk (the sum in front of it is zero or not finite, or this is
+        // the wave's last, partial chunk): the walk reads the summaries before anything else, so they
+        // have to say so themselves
         WideSum<S> none;
         for (int p = 0; p < 2; p++) { none.of[p].lo = none.of[p].hi = none.of[p].step = 0; none.of[p].e = WIDE_NO_E(S); }
-        if (t < WIDE_K) ws.maps[c * WIDE_K + t] = none;
-        else ws.subs[c * (WIDE_K * WIDE_SUBS) + (t - WIDE_K)] = none;
+#pragma unroll
+        for (int cand = 0; cand < WIDE_K; cand++) s_sub[cand * WIDE_SUBS + wave] = none;
     }
+    if (lane == 63 && badw) {
+        uint32_t bits = 0;
+#pragma unroll
+        for (int cand = 0; cand < WIDE_K; cand++) if ((badw >> cand) & 1u) bits |= (1u << cand) | wide_bad_sub(cand, wave);
+        atomicOr(&s_bad, bits);
+    }
+    __syncthreads();
+    if (t < WIDE_K * WIDE_SUBS) ws.subs[c * (WIDE_K * WIDE_SUBS) + t] = s_sub[t];
+    if (t < WIDE_K) {
+        // (thread `cand` puts slot `cand` of the sub-chunks together; a slot on whose exponent they do not
+        // agree comes out as a summary for none, and is crossed out for the chunk)
+        WideSum<S> out = s_sub[t * WIDE_SUBS];
+        for (uint32_t w = 1; w < WIDE_SUBS; w++) out = wide_then<T>(out, s_sub[t * WIDE_SUBS + w]);
+        ws.maps[c * WIDE_K + t] = out;
+        const bool none = out.of[0].e == WIDE_NO_E(S);
+        if (none) atomicOr(&s_bad, 1u << t);
+        if (t == 1) {
+            // Is the walk likely to open this chunk?  Slot 1 of sub-chunk 0 is the exponent of the rough
+            // sum in front of the chunk: the walk's own test on that sum, with a margin for how far the
+            // exact chain may be from it.  (Only a hint: the walk loads hinted chunks ahead of time.)
+            bool hint = none || (s_bad & 2u) != 0;
+            if (!hint) {
+                const S sa = (S)scalbn(a, G::MANT - (head.e0 + 1));
+                const S margin = (S)1 << (G::MANT - 8);
+                for (int p = 0; p < 2; p++) hint = hint || !wide_inside<T>(sa + out.of[p].lo, sa + out.of[p].hi, margin);
+            }
+            if (hint) atomicOr(&s_bad, WIDE_HINT);
+        }
+    }
+    __syncthreads();
+    head.bad = s_bad;
     if ((head.bad & WIDE_CHUNK_BITS) == WIDE_CHUNK_BITS) head.bad |= WIDE_HINT;
     if (t == 0) ws.heads[c] = head;
 }
@@ -504,9 +547,10 @@ template <typename T> __device__ __forceinline__ uint32_t wide_take_many(T &acc,
 // whose summaries were looked at, `taken` those of them that went in one step.
 template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len, uint32_t &taken, uint32_t &tried)
 {
-    uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate
+    uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate ...
 #pragma unroll
     for (int cand = 0; cand < WIDE_K; cand++) forced &= head.bad >> (4 + cand * WIDE_SUBS);
+    forced |= (head.bad >> WIDE_SKIP_SHIFT) & ((1u << WIDE_SUBS) - 1u);        // ... or not expected to go in one step
     uint32_t w = 0;
     while (w * 64u * WIDE_EPL < len) {
         const uint32_t at = w * 64u * WIDE_EPL;
@@ -667,7 +711,9 @@ __device__ __forceinline__ void wide_walk_body(const FilterIn &in, void *ws_base
                 // the sub-chunk goes in one step.  The walk keeps a balance of that, in additions: while it
                 // is clearly negative (a sum that changes its binade every few hundred packets), opened
                 // chunks are added whole, and every eighth tries again.
-                const bool hopeless = (head.bad & WIDE_SUB_BITS) == WIDE_SUB_BITS;     // every sub-chunk crossed out for every candidate
+                // every sub-chunk crossed out for every candidate, or not expected to go in one step
+                const bool hopeless = (((head.bad >> 4) & (head.bad >> (4 + WIDE_SUBS)) & (head.bad >> (4 + 2 * WIDE_SUBS))) | (head.bad >> WIDE_SKIP_SHIFT)) % (1u << WIDE_SUBS)
+                                      == (1u << WIDE_SUBS) - 1u;
                 if (hopeless || (balance < -WIDE_OWES && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val[cur], len);
                 else {
                     uint32_t taken = 0, tried = 0;
