@@ -3,17 +3,18 @@
 //
 // k_filter_flat_scan keeps everything in one workgroup because each round needs the sum the round
 // before it left.  What a round needs of that sum, though, is little: its exponent e (which fixes the
-// grid) and, at the very end, its integer S.  So the packets are cut into chunks of 1,024, and a
-// first pass guesses every chunk's exponent from an ordinary (inexact, parallel) prefix sum of the
-// wave -- the exact chain cannot be far from it -- and works out, for the guess and its two
-// neighbours, what the chunk does to ANY sum of that exponent, of either parity p:
-//     step   the chunk's total step on S
-//     lo, hi the least and the greatest exact partial sum inside the chunk, relative to S
-// (a chunk's packets are parity maps; their composition and the running offsets come out of a
-// wavefront scan per candidate exponent).  Such summaries compose like the maps themselves
-// (wide_then), which is used twice: a chunk's summary is put together from those of its four
-// wavefronts (sub-chunks of 256 packets, kept as well), and the walk puts the summaries of up to 64
-// chunks together to step over all of them at once.
+// grid) and, at the very end, its integer S.  So the packets are cut into chunks of 1,024 (four
+// sub-chunks of 256, a wavefront each), and a first pass guesses the sum's exponent in front of every
+// sub-chunk from an ordinary (inexact, parallel) prefix sum of the wave -- the exact chain cannot be
+// far from it -- and works out, for the guess and its two neighbours, what the sub-chunk does to ANY
+// sum of that exponent, of either parity p:
+//     step   the sub-chunk's total step on S
+//     lo, hi the least and the greatest exact partial sum inside it, relative to S
+// (the packets are parity maps; their composition and the running offsets come out of a wavefront
+// scan per candidate exponent).  Such summaries compose like the maps themselves (wide_then), which
+// is used twice: a chunk's summary is put together from those of its four sub-chunks (where they
+// agree on the exponent -- they do unless the rough sum changes its binade inside the chunk), and
+// the walk puts the summaries of up to 64 chunks together to step over all of them at once.
 // The last pass is one workgroup walking the chunks in order: if the sum's exponent is one of the
 // chunk's candidates and S + lo .. S + hi stays inside the binade, the whole chunk is S += step;
 // otherwise (the first chunk, a chunk in which the sum changes its binade, non-finite values, a bad
