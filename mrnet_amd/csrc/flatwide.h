@@ -41,14 +41,6 @@
 #define WIDE_CHUNK ((uint32_t)(WIDE_TPB * WIDE_EPL))
 #define WIDE_K 3                        // candidate exponents per chunk: guess - 1, guess, guess + 1
 #define WIDE_STAGE 128u                 // chunk summaries the walk keeps in LDS at a time
-#ifndef WIDE_LOOK
-#define WIDE_LOOK 48u                   // additions that looking at one sub-chunk's summaries is priced at
-#endif
-#ifndef WIDE_OWES
-#define WIDE_OWES 400                   // the balance below which opened chunks are added whole
-#endif
-// (measured on ten zero-mean draws and the hostile kinds: 24 / 48 / 92 and no giving up at all end
-// within 3 % of one another on the draws; 48 and 92 are 9 % ahead on data that never pays)
 #ifndef WIDE_MANY_MIN
 #define WIDE_MANY_MIN 4u                // chunks the hints promise in a row from which the walk takes them many at a time
 #endif
@@ -549,9 +541,9 @@ template <typename T> __device__ __forceinline__ uint32_t wide_take_many(T &acc,
 // A chunk the walk could not take in one step (one wavefront; the chunk's packets in s_val, its
 // sub-chunk summaries in s_sub): sub-chunk by sub-chunk, each in one step where its test holds for the
 // sum in front of it, the plain way otherwise.  Sub-chunks that no sum can take in one step (every
-// candidate crossed out) are added in one go with their neighbours.  `tried` counts the sub-chunks
-// whose summaries were looked at, `taken` those of them that went in one step.
-template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len, uint32_t &taken, uint32_t &tried)
+// candidate crossed out, or marked by the second pass as not worth a look) are added in one go with their
+// neighbours.
+template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHead head, const WideSum<typename Grid<T>::S> *s_sub, const T *s_val, uint32_t len)
 {
     uint32_t forced = (1u << WIDE_SUBS) - 1u;                   // bit w: sub-chunk w is crossed out for every candidate ...
 #pragma unroll
@@ -561,8 +553,7 @@ template <typename T> __device__ __forceinline__ T wide_open(T acc, const WideHe
     while (w * 64u * WIDE_EPL < len) {
         const uint32_t at = w * 64u * WIDE_EPL;
         if (!((forced >> w) & 1u) && len - at >= 64u * WIDE_EPL) {
-            tried++;
-            if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; taken++; continue; }
+            if (wide_take<T>(acc, &s_sub[w], WIDE_SUBS)) { w++; continue; }
             acc = plain_fold<T>(acc, s_val + at, 64u * WIDE_EPL);
             w++;
             continue;
@@ -625,8 +616,6 @@ __device__ __forceinline__ void wide_walk_body(const FilterIn &in, void *ws_base
     static_assert(SUB_DW <= LOADERS, "one word of the sub-chunk summaries per loading thread");
     const uint32_t u = t - 64u;                                 // (loading threads: 0 .. LOADERS - 1)
     WideRaw<T> ahead[LEPL];
-    int32_t balance = 0;                                        // (wavefront 0's: what looking at sub-chunk summaries has saved, in additions)
-    uint32_t skipped = 0;
     uint32_t sub_ahead = 0;
     uint64_t ahead_of = ~(uint64_t)0;
 #define WIDE_FETCH(cc_) do { \
@@ -714,19 +703,14 @@ __device__ __forceinline__ void wide_walk_body(const FilterIn &in, void *ws_base
             if (wave == 0) {
                 // (values behind len are staged but not added)
                 // Looking at a sub-chunk's summaries costs what some 90 additions cost, and saves 256 if
-                // the sub-chunk goes in one step.  The walk keeps a balance of that, in additions: while it
-                // is clearly negative (a sum that changes its binade every few hundred packets), opened
-                // chunks are added whole, and every eighth tries again.
-                // every sub-chunk crossed out for every candidate, or not expected to go in one step
+                // the sub-chunk goes in one step: the second pass has marked the sub-chunks that will
+                // probably not (a running balance of looks that paid, kept by the walk on top of those
+                // marks, made no measurable difference).
+                // Every sub-chunk crossed out for every candidate, or not expected to go in one step:
                 const bool hopeless = (((head.bad >> 4) & (head.bad >> (4 + WIDE_SUBS)) & (head.bad >> (4 + 2 * WIDE_SUBS))) | (head.bad >> WIDE_SKIP_SHIFT)) % (1u << WIDE_SUBS)
                                       == (1u << WIDE_SUBS) - 1u;
-                if (hopeless || (balance < -WIDE_OWES && (++skipped & 7u) != 0)) acc = plain_fold<T>(acc, s_val[cur], len);
-                else {
-                    uint32_t taken = 0, tried = 0;
-                    acc = wide_open<T>(acc, head, s_sub[cur], s_val[cur], len, taken, tried);
-                    balance += (int32_t)(taken * 64u * WIDE_EPL) - (int32_t)(tried * WIDE_LOOK);
-                    balance = balance > 2048 ? 2048 : (balance < -2048 ? -2048 : balance);
-                }
+                if (hopeless) acc = plain_fold<T>(acc, s_val[cur], len);
+                else acc = wide_open<T>(acc, head, s_sub[cur], s_val[cur], len);
                 if (lane == 0) s_acc[cur] = acc;
             }
             __syncthreads();
