@@ -79,8 +79,8 @@ enum mrpdr_filter_op { MRPDR_SUM = 0, MRPDR_MIN = 1, MRPDR_MAX = 2, MRPDR_AVG = 
  *                     addition rounds -- by the chain of additions itself, which waves
  *                     of 8,192 packets and more take a binade at a time with a scan over
  *                     the sum's integer grid instead of one dependent addition per packet
- *                     (from 16,384 floats or 8,192 doubles on with that work spread over the
- *                     whole device)
+ *                     (with that work spread over the whole device wherever the caller's ctx,
+ *                     or the no-allocation entry point's built-in array, has room for it)
  *   MRPDR_SHAPE_FLAT_SERIAL  the same result with float / double SUM and AVG computed by
  *                     the plain chain only, one addition after the other as the reference's
  *                     loop is written (for cross-checks; identical bits, slower on large

@@ -1237,12 +1237,14 @@ static int32_t run_tree_link(const FilterWs &fw, const FilterIn &in, FilterLink 
 // Below this many packets the scan's rounds do not pay (measured, growing sums: 4,096 floats 22 us
 // against the plain chain's 17, 8,192: 31 against 33, 16,383: 44 against 64).
 #define FLAT_SCAN_MIN 8192
-// From here on three launches over the whole device beat the one workgroup.  For doubles, whose
-// rounds cost the one workgroup more, already from 8,192 (measured on growing sums: 33 against 42 us
-// there, 45 against 63 at 16,383; floats 28 against 31 and 38 against 44, which is within what data
-// that opens every chunk loses: 5-8 us).
+// From here on three launches over the whole device beat the one workgroup, for both types (measured,
+// floats, the one workgroup against the device-wide form against the plain chain: growing sums of
+// 8,192 packets 31 / 26 / 35 us, of 16,383 packets 47 / 36 / 68; zero-mean draws 52 / 45 / 35 and
+// 86 / 55-75 / 68 -- between these sizes neither exact form catches the chain on data whose sum hovers
+// around zero, the two passes being a third of such a call; data that opens every chunk 37-49 / 42-47 / 35
+// and 71-83 / 76-80 / 68).  The one workgroup is left with callers that have no room for the summaries.
 #ifndef FLAT_WIDE_MIN
-#define FLAT_WIDE_MIN 16384
+#define FLAT_WIDE_MIN 8192
 #endif
 #define FLAT_WIDE_MIN_DOUBLE 8192
 

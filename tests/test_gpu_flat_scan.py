@@ -176,3 +176,27 @@ def test_scan_over_packets_of_both_byte_orders(codec, t, dt, n):
             assert same_value(got[0], ref[0]), (kind, n, op, got, ref)
             if op == O.AVG:
                 assert got[1] == ref[1]
+
+
+@pytest.mark.parametrize("t,dt,n", [(O.FLOAT_T, np.float32, 600001), (O.DOUBLE_T, np.float64, 300001)])
+def test_one_workgroup_scan_for_callers_without_room(codec, t, dt, n):
+    """The one-workgroup form of the scan (k_filter_flat_scan) is what callers without room for the
+    device-wide form's summaries get: mrpdr_wave_filter_noalloc beyond what its built-in array holds
+    (536,000 floats, 273,000 doubles).  Same data kinds, against the oracle's chain and against the
+    ctx entry point (which takes the device-wide form)."""
+    from mrnet_amd import capi
+    lib = capi.load()
+    st = torch.cuda.current_stream().cuda_stream
+    for name, vals in datasets(dt, n, 5 * n + t).items():
+        dv = codec.to_device(vals)
+        res = torch.zeros(16, dtype=torch.uint8, device=codec.device)
+        ok = torch.zeros(1, dtype=torch.int32, device=codec.device)
+        assert lib.mrpdr_wave_filter_noalloc(O.SUM, int(t), W.SHAPE_FLAT, dv.data_ptr(), np.dtype(dt).itemsize, None, 0,
+                                             n, 0, res.data_ptr(), ok.data_ptr(), st) == 1, capi.last_error()
+        torch.cuda.synchronize()
+        got = W.result_value(res, ok, np.dtype(dt), O.SUM)
+        wide = W.result_value(*codec.filter_columns(O.SUM, t, dv, None, W.SHAPE_FLAT), np.dtype(dt), O.SUM)
+        with np.errstate(all="ignore"):
+            ref = O.filter_flat(O.SUM, t, vals)
+        assert same_value(got[0], ref[0]), (name, n, "one workgroup vs oracle", got[0], ref[0])
+        assert same_value(got[0], wide[0]), (name, n, "one workgroup vs device-wide", got[0], wide[0])

@@ -5,7 +5,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from mrnet_amd import wave as W
-n = 65536
+n = int(os.environ.get("PROBE_N", "65536"))
 codec = W.Codec(max_packets=n)
 dev = codec.device
 res = torch.empty(16, dtype=torch.uint8, device=dev)
