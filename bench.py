@@ -384,6 +384,15 @@ def small_wave_extras(codec):
             codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
                              n5, 0, W.SHAPE_TREE, r, rok)
     out["c5_shard_us_per_wave_three_filters"] = round(time_call(c5, 200) * 1e6, 2)
+    # the same three filters as ONE reference call each over the shard (MRPDR_SHAPE_FLAT, what the mirrors
+    # default to): Min and Max level by level with the NaN rule carried along, Avg by the exact chain
+    rf = [torch.empty(16, dtype=torch.uint8, device=dev) for _ in range(3)]
+
+    def c5_one_call():
+        for r, op in zip(rf, (W.TFILTER_MIN, W.TFILTER_MAX, W.TFILTER_AVG)):
+            codec.filter_raw(op, W.DataType.DOUBLE_T, w5.arena.data_ptr(), 12, w5.arena.data_ptr() + 8, 12,
+                             n5, 0, W.SHAPE_FLAT, r, rok)
+    out["c5_shard_us_per_wave_one_reference_call_each"] = round(time_call(c5_one_call, 100) * 1e6, 2)
     r48 = torch.empty(48, dtype=torch.uint8, device=dev)
     ok3 = torch.empty(3, dtype=torch.int32, device=dev)
 
